@@ -1,0 +1,165 @@
+/*
+ * include/nbk.h -- C-ABI of libnbk (numbotics_amd/csrc), the MI355X (gfx950) batched kinematics +
+ * collision-validity engine.
+ *
+ * The reference (landonclark97/numbotics) has no FFI layer: its de-facto kernel ABI is the numba
+ * signatures of the two batched kernels plus the Python methods that wrap PyBullet (SURVEY.md
+ * section 8b).  Each entry point below names the reference interface it replaces; paths are relative
+ * to the reference repository root.
+ *
+ * Conventions
+ *   - plain pointers and sizes, no torch types; every array pointer that is not marked "host" is a
+ *     DEVICE pointer (hipMalloc / torch.cuda tensor.data_ptr()) on the current device;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
+ *     with respect to the host and capturable into a hipGraph (no allocation, no synchronisation);
+ *   - float64 everywhere (the reference computes in float64); q is row-major (B, n_q);
+ *   - return value: NBK_OK or a negative status; no exceptions cross the boundary;
+ *   - a descriptor is immutable after creation and may be shared by streams and threads.
+ */
+#ifndef NBK_H
+#define NBK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBK_ABI_VERSION 1
+
+enum {
+    NBK_OK = 0,
+    NBK_ERR_INVALID = -1,      /* bad argument (null pointer, negative size, bad index) */
+    NBK_ERR_NO_DEVICE = -2,    /* no HIP device / not a gfx950 code object for this device */
+    NBK_ERR_HIP = -3,          /* a HIP runtime call failed; see nbk_last_error() */
+    NBK_ERR_UNSUPPORTED = -4,  /* descriptor exceeds a compiled-in limit */
+    NBK_ERR_ALLOC = -5
+};
+
+/* shape / joint codes used inside descriptors */
+enum { NBK_SPHERE = 0, NBK_CAPSULE = 1, NBK_BOX = 2, NBK_CYLINDER = 3, NBK_PLANE = 4 };
+enum { NBK_REVOLUTE = 0, NBK_PRISMATIC = 1 };
+enum { NBK_CONNECT = 0, NBK_STEER = 1 };
+
+#define NBK_MAX_JOINTS 32
+#define NBK_MAX_DOF 32
+
+/*
+ * Flat robot + scene description ("compile the robot": replaces the per-frame flattening of
+ * numbotics/robots/arm.py:17-71 and the per-query shape/pair bookkeeping of arm.py:190-250,555-580).
+ * All pointers are HOST pointers; nbk_model_create copies everything to the device.
+ */
+typedef struct {
+    int32_t n_q;                  /* degrees of freedom (columns of q) */
+    int32_t n_joints;             /* movable joints = moving frames, parents first */
+    const int32_t *joint_parent;  /* [J] parent moving frame, -1 = base */
+    const int32_t *joint_type;    /* [J] NBK_REVOLUTE / NBK_PRISMATIC */
+    const int32_t *joint_qidx;    /* [J] column of q */
+    const double *joint_rot;      /* [J][27] M0 = R K, M1 = R (K - I), M2 = R [a]x (3x3 row-major each);
+                                     local rotation = M0 - cos(q) M1 + sin(q) M2 (robots/helpers.py:43-55) */
+    const double *joint_trans;    /* [J][3] translation of the (fixed-merged) joint offset */
+    const double *joint_slide;    /* [J][3] R a for prismatic joints, 0 otherwise */
+    const double *joint_axis;     /* [J][3] joint axis in the joint frame */
+    const double *base_pose;      /* [12] 3x4 row-major */
+    int32_t n_rshapes;            /* robot collision primitives */
+    const int32_t *rshape_frame;  /* [S] moving frame carrying the shape, -1 = base */
+    const int32_t *rshape_type;   /* [S] NBK_SPHERE / CAPSULE / BOX / CYLINDER */
+    const double *rshape_local;   /* [S][12] pose of the primitive in its moving frame */
+    const double *rshape_param;   /* [S][4] sphere r | capsule r,hl | cylinder r,hl | box hx,hy,hz ; [3] = margin */
+    int32_t n_wshapes;            /* static world primitives (obstacles) */
+    const int32_t *wshape_type;   /* [W] the above or NBK_PLANE (param[0..2] = unit normal) */
+    const double *wshape_pose;    /* [W][12] world pose */
+    const double *wshape_param;   /* [W][4] */
+    int32_t n_pairs;              /* allowed (shape, shape) pairs, sorted by pair_a */
+    const int32_t *pair_a;        /* [P] robot shape */
+    const int32_t *pair_b;        /* [P] robot shape (< S) or S + world shape */
+} nbk_model_desc;
+
+typedef struct nbk_model nbk_model;
+
+int32_t nbk_abi_version(void);
+const char *nbk_status_string(int32_t status);
+const char *nbk_last_error(void);          /* text of the last HIP failure on this thread */
+int32_t nbk_device_count(void);            /* 0 when no GPU is visible; never fails */
+
+int32_t nbk_model_create(const nbk_model_desc *desc, nbk_model **out);
+void nbk_model_destroy(nbk_model *m);
+int32_t nbk_model_num_pairs(const nbk_model *m);
+
+/*
+ * Batched forward kinematics of one frame.
+ * Replaces nb_compute_transformation + nb_joint_transform (numbotics/robots/helpers.py:33-113) as
+ * called by Arm.forward_kinematics (numbotics/robots/arm.py:369-410).
+ *   path  (host) [path_len] joint indices root -> frame;  local (host) [12] constant pose after the last
+ *   joint (trailing fixed joints, COM offset, a single local_pose);  local_pose (device, optional)
+ *   [B][16] per-configuration right factor;  T_out (device) [B][16] row-major 4x4.
+ */
+int32_t nbk_fk_batch(const nbk_model *m, const double *q, int64_t B, const int32_t *path, int32_t path_len,
+                     const double *local, const double *local_pose, double *T_out, void *stream);
+
+/*
+ * Batched geometric Jacobian [v; w] of one frame.
+ * Replaces nb_compute_jacobian (numbotics/robots/helpers.py:117-187) as called by Arm.jacobian
+ * (numbotics/robots/arm.py:413-461).  mode 0: end pose = T*local; 1: T*local*pose[b] (local_pose);
+ * 2: end position = translation of pose[b] (global_pose).  J_out (device) [B][6][n_q].
+ */
+int32_t nbk_jacobian_batch(const nbk_model *m, const double *q, int64_t B, const int32_t *path,
+                           int32_t path_len, const double *local, int32_t mode, const double *pose,
+                           double *J_out, void *stream);
+
+/*
+ * Batched Arm.in_collision (numbotics/robots/arm.py:603-604): bit b of mask_bits / mask_bytes[b] is 1
+ * iff min over the allowed pairs of the signed distance is < threshold (strict).  Replaces the
+ * per-configuration PyBullet round trip Arm.collisions -> Chain.distance_to -> getClosestPoints
+ * (arm.py:555-580, numbotics/physics/chain.py:944-969).
+ *   mask_bits  (device, optional) [ceil(B/64)] uint64, bit (b % 64) of word (b / 64);
+ *   mask_bytes (device, optional) [B] uint8.  At least one must be given.
+ */
+int32_t nbk_validity_batch(const nbk_model *m, const double *q, int64_t B, double threshold,
+                           uint64_t *mask_bits, uint8_t *mask_bytes, void *stream);
+
+/*
+ * Batched Arm.closest_to (arm.py:599-600): min signed distance and the index of the pair attaining it
+ * (first minimum in pair order; -1 / +inf when there are no pairs).
+ */
+int32_t nbk_closest_batch(const nbk_model *m, const double *q, int64_t B, double *min_dist,
+                          int32_t *argmin, void *stream);
+
+/*
+ * Batched Arm.collisions (arm.py:555-580): signed distance of every allowed pair, dist [B][P], and
+ * optionally the Proximity fields (numbotics/physics/collision.py:25-32) witness [B][P][9] =
+ * position on subject, position on target, unit normal from target to subject.
+ */
+int32_t nbk_pair_distances_batch(const nbk_model *m, const double *q, int64_t B, double *dist,
+                                 double *witness, void *stream);
+
+/*
+ * Batched DiscreteConnector.connect / steer (numbotics/planning/sampling_based/connectors.py:57-100)
+ * with the default linear trajectory (numbotics/planning/trajectories.py:6-22) and
+ * validity_checker = not in_collision(q, threshold).
+ *   starts, goals [E][n_q]; dist (optional) [E] = distance_func(start, goal), NULL = Euclidean norm;
+ *   valid [E] uint8: 1 iff every sample T = arange(0, T_f, resolution/d) U {T_f} is collision free,
+ *   0 also for d <= float32 eps (the reference returns None);
+ *   end (optional) [E][n_q]: goal (connect) or traj(T_f) (steer), NaN for the degenerate edge;
+ *   n_samples (optional) [E] int32 = len(T).
+ */
+int32_t nbk_edge_validity_batch(const nbk_model *m, const double *starts, const double *goals,
+                                const double *dist, int64_t E, double resolution, double max_distance,
+                                int32_t mode, double threshold, uint8_t *valid, double *end,
+                                int32_t *n_samples, void *stream);
+
+/* Arithmetic-contract self test: elementwise sincos(a), sqrt(a), a/b computed by the device routines
+ * the kernels use (all arrays device, length n). */
+int32_t nbk_selftest_math(const double *a, const double *b, int64_t n, double *sin_out, double *cos_out,
+                          double *sqrt_out, double *div_out, void *stream);
+
+/* Host-buffer conveniences for callers without a device allocator (PCIe inclusive; they allocate,
+ * copy, run, copy back and synchronise). */
+int32_t nbk_fk_batch_host(const nbk_model *m, const double *q, int64_t B, const int32_t *path,
+                          int32_t path_len, const double *local, double *T_out);
+int32_t nbk_validity_batch_host(const nbk_model *m, const double *q, int64_t B, double threshold,
+                                uint8_t *mask_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

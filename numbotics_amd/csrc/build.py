@@ -1,0 +1,45 @@
+"""Build numbotics_amd/csrc/libnbk.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m numbotics_amd.csrc.build [--force]
+
+-ffp-contract=off is part of the arithmetic contract: the only fused multiply-adds are
+the ones written as NBK_FMA in the sources.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libnbk.so")
+SOURCES = ["nbk.hip", "nbk_device.hpp", os.path.join("..", "..", "include", "nbk.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    return all(os.path.getmtime(os.path.join(HERE, s)) <= t for s in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and up_to_date():
+        return LIB
+    cmd = [hipcc()] + FLAGS + [os.path.join(HERE, "nbk.hip"), "-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,819 @@
+// nbk.hip -- gfx950 kernels + the C-ABI of include/nbk.h.
+//
+// Mapping: ONE CONFIGURATION PER LANE, one 64-lane wave per workgroup.
+//   * q rows are fetched with coalesced 16-byte loads into LDS and read back transposed, outputs
+//     (poses, Jacobians) go through an LDS transpose so that every global access is a contiguous
+//     1 KiB-per-instruction stream;
+//   * the robot/scene descriptor is wave-uniform: it is read through scalar loads, and every branch on a
+//     joint type / shape kind / pair index is a scalar branch;
+//   * the collision kernels sweep the kinematic tree once, keep the current frame in VGPRs and park the
+//     world-frame core of every robot shape in LDS as [component][lane] rows (conflict-free ds_read_b64);
+//     pairs are then evaluated from LDS + scalar constants;
+//   * the validity bit mask is one __ballot per wave = one 64-bit word per workgroup.
+// No MFMA: this is a transform chain + branchy narrowphase, not a contraction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/nbk.h"
+#include "nbk_device.hpp"
+
+namespace nbk {
+
+// ---- device-resident descriptor -----------------------------------------------------------------
+struct DevModel {
+    int n_q, n_joints, n_rshapes, n_wshapes, n_pairs;
+    int shape_rows;   // LDS rows (of 64 doubles) holding robot shape cores
+    int frame_slots;  // saved frames (tree branches)
+    const int* joint_type;        // [J]
+    const int* joint_qidx;        // [J]
+    const int* joint_load;        // [J] -2: parent is the frame in registers, -1: base, >=0: saved slot
+    const int* joint_save;        // [J] slot to park this frame in, or -1
+    const int* joint_shape_begin; // [J+2] robot shapes (in `order`) of frame k-1 are [begin[k], begin[k+1])
+    const double* joint_rot;      // [J][27]
+    const double* joint_trans;    // [J][3]
+    const double* joint_slide;    // [J][3]
+    const double* joint_axis;     // [J][3]
+    const double* base_pose;      // [12]
+    const int* rs_kind;           // [S] core kind, in frame order
+    const int* rs_row;            // [S] first LDS row
+    const double* rs_local;       // [S][12]
+    const double* rs_core;        // [S][5] h0 h1 h2 rad margin
+    const int* ws_kind;           // [W]
+    const double* ws_core;        // [W][17] c(3) ax(9: ax0 ax1 ax2) h(3) rad margin
+    const int* pair_a;            // [P] index into rs_* (frame order)
+    const int* pair_b;            // [P] < S robot (frame order), else S + world
+    const int* pair_user;         // [P] index of this pair in the caller's pair list
+};
+
+}  // namespace nbk
+
+struct nbk_model {
+    nbk::DevModel d;
+    void* blob;
+    size_t blob_bytes;
+    int device;
+    int n_pairs;
+    int n_q;
+    int n_joints;
+};
+
+namespace nbk {
+
+static thread_local char g_err[256] = "";
+
+static int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return NBK_ERR_HIP;
+}
+#define NBK_HIP(call)                                           \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);       \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+NBK_DEV int core_rows(int kind) { return kind == K_POINT ? 3 : (kind == K_BOX ? 12 : 6); }
+
+// ---- q staging: rows [B][n_q] -> LDS [n_q][64] ---------------------------------------------------
+// The block's slab of q is contiguous (64*n_q doubles); it is read with 16-byte loads where the slab is
+// full, then each lane picks its own row out of LDS.
+NBK_DEV void stage_q(const double* __restrict__ q, int64_t base, int64_t B, int n_q, double* lds_raw, double* lds_q, int lane) {
+    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+    const int total = (int)rows * n_q;
+    const double* src = q + base * n_q;
+    if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+        const double2* s2 = reinterpret_cast<const double2*>(src);
+        double2* d2 = reinterpret_cast<double2*>(lds_raw);
+        for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
+    } else {
+        for (int i = lane; i < total; i += WAVE) lds_raw[i] = src[i];
+    }
+    __syncthreads();
+    if (lane < rows) {
+        for (int j = 0; j < n_q; ++j) lds_q[j * WAVE + lane] = lds_raw[lane * n_q + j];
+    } else {
+        for (int j = 0; j < n_q; ++j) lds_q[j * WAVE + lane] = 0.0;
+    }
+    __syncthreads();
+}
+
+// child frame of joint k (robots/helpers.py:43-55 restated with the host-made M0/M1/M2)
+NBK_DEV void joint_apply(const DevModel& m, int k, const Xf& parent, double qk, Xf& out) {
+    const double* M = m.joint_rot + 27 * k;
+    const double* toff = m.joint_trans + 3 * k;
+    const double* sl = m.joint_slide + 3 * k;
+    double s = 0.0, c = 0.0;
+    if (m.joint_type[k] == NBK_REVOLUTE) nbk_sincos(qk, s, c);
+    double L[9], tl[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L[e] = NBK_FMA(s, M[18 + e], NBK_FMA(-c, M[9 + e], M[e]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tl[i] = NBK_FMA(qk, sl[i], toff[i]);
+    xf_mul(parent, L, tl, out);
+}
+
+// ---- FK of one frame -----------------------------------------------------------------------------
+struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; };
+
+// LDS: raw q slab (64*n_q) | q transposed (n_q*64) | output rows (64 * 17)
+__global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const double* __restrict__ q, int64_t B,
+                                            const double* __restrict__ local_pose, double* __restrict__ T_out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    double* lds_raw = lds;
+    double* lds_q = lds + WAVE * m.n_q;
+    double* lds_o = lds_q + WAVE * m.n_q;
+    stage_q(q, base, B, m.n_q, lds_raw, lds_q, lane);
+    Xf T;
+    xf_from12(m.base_pose, T);
+    for (int i = 0; i < path.len; ++i) {
+        const int k = path.idx[i];
+        const double qk = lds_q[m.joint_qidx[k] * WAVE + lane];
+        Xf nxt;
+        joint_apply(m, k, T, qk, nxt);
+        T = nxt;
+    }
+    Xf loc, E;
+    xf_from12(path.local, loc);
+    xf_mul(T, loc.R, loc.t, E);
+    const int64_t b = base + lane;
+    if (local_pose != nullptr && b < B) {
+        const double* lp = local_pose + 16 * b;
+        Xf P, E2;
+        xf_from12(lp, P);
+        xf_mul(E, P.R, P.t, E2);
+        E = E2;
+    }
+    // transpose through LDS (row stride 17 doubles: conflict-free ds_write_b64)
+    double* row = lds_o + lane * 17;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        row[4 * i] = E.R[3 * i]; row[4 * i + 1] = E.R[3 * i + 1]; row[4 * i + 2] = E.R[3 * i + 2];
+        row[4 * i + 3] = E.t[i];
+    }
+    row[12] = 0.0; row[13] = 0.0; row[14] = 0.0; row[15] = 1.0;
+    __syncthreads();
+    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+    double2* dst = reinterpret_cast<double2*>(T_out + base * 16);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int g = lane + WAVE * kk;   // double2 index inside the block's 1024-double slab
+        const int r = g >> 3, c2 = (g & 7) * 2;
+        if (r < rows) {
+            double2 v;
+            v.x = lds_o[r * 17 + c2];
+            v.y = lds_o[r * 17 + c2 + 1];
+            dst[g] = v;
+        }
+    }
+}
+
+// ---- geometric Jacobian of one frame ---------------------------------------------------------------
+// LDS: raw q | q transposed | joint origins+axes [path_len*6][64] | output rows 64 * (6*n_q + 1)
+__global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const double* __restrict__ q, int64_t B,
+                                                  int mode, const double* __restrict__ pose, double* __restrict__ J_out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nq = m.n_q;
+    double* lds_raw = lds;
+    double* lds_q = lds + WAVE * nq;
+    double* lds_f = lds_q + WAVE * nq;
+    double* lds_o = lds_f + WAVE * 6 * path.len;
+    stage_q(q, base, B, nq, lds_raw, lds_q, lane);
+    Xf T;
+    xf_from12(m.base_pose, T);
+    for (int i = 0; i < path.len; ++i) {
+        const int k = path.idx[i];
+        const double qk = lds_q[m.joint_qidx[k] * WAVE + lane];
+        Xf nxt;
+        joint_apply(m, k, T, qk, nxt);
+        T = nxt;
+        const double* a = m.joint_axis + 3 * k;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            lds_f[(6 * i + r) * WAVE + lane] = T.t[r];
+            lds_f[(6 * i + 3 + r) * WAVE + lane] = NBK_FMA(T.R[3 * r + 2], a[2], NBK_FMA(T.R[3 * r + 1], a[1], T.R[3 * r] * a[0]));
+        }
+    }
+    Xf loc, E;
+    xf_from12(path.local, loc);
+    xf_mul(T, loc.R, loc.t, E);
+    const int64_t b = base + lane;
+    double pend[3] = {E.t[0], E.t[1], E.t[2]};
+    if (mode == 1 && b < B) {
+        Xf P;
+        xf_from12(pose + 16 * b, P);
+        xf_mul_pos(E, P.t, pend);
+    } else if (mode == 2 && b < B) {
+        pend[0] = pose[16 * b + 3]; pend[1] = pose[16 * b + 7]; pend[2] = pose[16 * b + 11];
+    }
+    const int ncol = 6 * nq;
+    const int stride = ncol + 1 + ((ncol + 1) & 1 ? 0 : 1);   // odd row stride: conflict-free
+    double* row = lds_o + lane * stride;
+    for (int c = 0; c < ncol; ++c) row[c] = 0.0;
+    for (int i = 0; i < path.len; ++i) {
+        const int k = path.idx[i];
+        const int col = m.joint_qidx[k];
+        double p[3], w[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { p[r] = lds_f[(6 * i + r) * WAVE + lane]; w[r] = lds_f[(6 * i + 3 + r) * WAVE + lane]; }
+        if (m.joint_type[k] == NBK_REVOLUTE) {
+            double d[3], v[3];
+            sub3(pend, p, d);
+            cross3(w, d, v);
+            row[0 * nq + col] = v[0]; row[1 * nq + col] = v[1]; row[2 * nq + col] = v[2];
+            row[3 * nq + col] = w[0]; row[4 * nq + col] = w[1]; row[5 * nq + col] = w[2];
+        } else {
+            row[0 * nq + col] = w[0]; row[1 * nq + col] = w[1]; row[2 * nq + col] = w[2];
+        }
+    }
+    __syncthreads();
+    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+    double* dst = J_out + base * ncol;
+    const int total = (int)rows * ncol;
+    for (int g = lane; g < total; g += WAVE) {
+        const int r = g / ncol, c = g - r * ncol;
+        dst[g] = lds_o[r * stride + c];
+    }
+}
+
+// ---- collision: sweep the tree, park robot cores in LDS ---------------------------------------------
+// LDS rows of 64 doubles: [n_q q rows][shape_rows][frame_slots * 12]
+NBK_DEV void sweep_and_park(const DevModel& m, double* lds_q, double* lds_s, double* lds_fr, int lane) {
+    Xf base;
+    xf_from12(m.base_pose, base);
+    Xf T = base;
+    for (int k = -1; k < m.n_joints; ++k) {
+        if (k >= 0) {
+            const int ld = m.joint_load[k];
+            Xf P;
+            if (ld == -2) P = T;
+            else if (ld == -1) P = base;
+            else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) P.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) P.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
+            }
+            const double qk = lds_q[m.joint_qidx[k] * WAVE + lane];
+            joint_apply(m, k, P, qk, T);
+            const int sv = m.joint_save[k];
+            if (sv >= 0) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) lds_fr[(sv * 12 + e) * WAVE + lane] = T.R[e];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) lds_fr[(sv * 12 + 9 + e) * WAVE + lane] = T.t[e];
+            }
+        }
+        const int s0 = m.joint_shape_begin[k + 1], s1 = m.joint_shape_begin[k + 2];
+        for (int s = s0; s < s1; ++s) {
+            const double* loc = m.rs_local + 12 * s;
+            double Rl[9], tl[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { Rl[3 * i] = loc[4 * i]; Rl[3 * i + 1] = loc[4 * i + 1]; Rl[3 * i + 2] = loc[4 * i + 2]; tl[i] = loc[4 * i + 3]; }
+            double* rows = lds_s + m.rs_row[s] * WAVE + lane;
+            double c[3];
+            xf_mul_pos(T, tl, c);
+            rows[0] = c[0]; rows[WAVE] = c[1]; rows[2 * WAVE] = c[2];
+            const int kind = m.rs_kind[s];
+            if (kind == K_SEG || kind == K_CYL) {
+                double u[3];
+                xf_mul_col(T, Rl, 2, u);
+                rows[3 * WAVE] = u[0]; rows[4 * WAVE] = u[1]; rows[5 * WAVE] = u[2];
+            } else if (kind == K_BOX) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    double u[3];
+                    xf_mul_col(T, Rl, j, u);
+                    rows[(3 + 3 * j) * WAVE] = u[0]; rows[(4 + 3 * j) * WAVE] = u[1]; rows[(5 + 3 * j) * WAVE] = u[2];
+                }
+            }
+        }
+    }
+}
+
+NBK_DEV void load_rcore(const DevModel& m, const double* lds_s, int s, int lane, Core& o) {
+    const double* rows = lds_s + m.rs_row[s] * WAVE + lane;
+    const double* cc = m.rs_core + 5 * s;
+    o.kind = m.rs_kind[s];
+    o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4];
+    o.c[0] = rows[0]; o.c[1] = rows[WAVE]; o.c[2] = rows[2 * WAVE];
+    if (o.kind == K_SEG || o.kind == K_CYL) {
+        o.ax[2][0] = rows[3 * WAVE]; o.ax[2][1] = rows[4 * WAVE]; o.ax[2][2] = rows[5 * WAVE];
+    } else if (o.kind == K_BOX) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            o.ax[j][0] = rows[(3 + 3 * j) * WAVE]; o.ax[j][1] = rows[(4 + 3 * j) * WAVE]; o.ax[j][2] = rows[(5 + 3 * j) * WAVE];
+        }
+    }
+}
+
+NBK_DEV void load_wcore(const DevModel& m, int w, Core& o) {
+    const double* cc = m.ws_core + 17 * w;
+    o.kind = m.ws_kind[w];
+    o.c[0] = cc[0]; o.c[1] = cc[1]; o.c[2] = cc[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { o.ax[j][0] = cc[3 + 3 * j]; o.ax[j][1] = cc[4 + 3 * j]; o.ax[j][2] = cc[5 + 3 * j]; }
+    o.h[0] = cc[12]; o.h[1] = cc[13]; o.h[2] = cc[14]; o.rad = cc[15]; o.margin = cc[16];
+}
+
+NBK_DEV void load_pair(const DevModel& m, const double* lds_s, int p, int lane, Core& A, Core& Bc) {
+    const int a = m.pair_a[p], b = m.pair_b[p];
+    load_rcore(m, lds_s, a, lane, A);
+    if (b < m.n_rshapes) load_rcore(m, lds_s, b, lane, Bc);
+    else load_wcore(m, b - m.n_rshapes, Bc);
+}
+
+// any allowed pair below thr?  (lane-local; the caller ballots)
+NBK_DEV bool lane_collides(const DevModel& m, const double* lds_s, int lane, double thr, bool active) {
+    bool hit = false;
+    for (int p = 0; p < m.n_pairs; ++p) {
+        // a lane that already has its answer idles; the wave leaves when every lane is done
+        if (__builtin_amdgcn_ballot_w64(active && !hit) == 0ull) break;
+        if (active && !hit) {
+            Core A, Bc;
+            load_pair(m, lds_s, p, lane, A, Bc);
+            if (cores_collide(A, Bc, thr)) hit = true;
+        }
+    }
+    return hit;
+}
+
+__global__ __launch_bounds__(64) void k_validity(DevModel m, const double* __restrict__ q, int64_t B, double thr,
+                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    double* lds_q = lds;
+    double* lds_s = lds_q + WAVE * m.n_q;
+    double* lds_fr = lds_s + WAVE * m.shape_rows;
+    // the raw slab is staged in the shape area (free until the sweep starts)
+    stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
+    const bool active = (base + lane) < B;
+    sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
+    const bool hit = lane_collides(m, lds_s, lane, thr, active);
+    const uint64_t word = __builtin_amdgcn_ballot_w64(hit && active);
+    if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
+    if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+}
+
+// MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses
+template <int MODE>
+__global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __restrict__ q, int64_t B,
+                                                   double* __restrict__ out_d, int32_t* __restrict__ out_i,
+                                                   double* __restrict__ out_w) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    double* lds_q = lds;
+    double* lds_s = lds_q + WAVE * m.n_q;
+    double* lds_fr = lds_s + WAVE * m.shape_rows;
+    stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
+    const int64_t b = base + lane;
+    const bool active = b < B;
+    sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
+    double best = NBK_INF;
+    int bi = -1;
+    for (int p = 0; p < m.n_pairs; ++p) {
+        Core A, Bc;
+        load_pair(m, lds_s, p, lane, A, Bc);
+        double wit[9];
+        const double d = cores_distance<MODE == 2>(A, Bc, wit);
+        if constexpr (MODE == 0) {
+            // pairs are visited in device order; ties resolve to the smallest USER index like the oracle
+            const int u = m.pair_user[p];
+            if (d < best || (d == best && u < bi)) { best = d; bi = u; }
+        } else {
+            if (active) {
+                const int64_t o = b * m.n_pairs + m.pair_user[p];
+                out_d[o] = d;
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) out_w[o * 9 + e] = wit[e];
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        if (active) { out_d[b] = best; if (out_i != nullptr) out_i[b] = bi; }
+    }
+}
+
+// ---- DiscreteConnector: one edge per wave, lanes = interpolation samples ---------------------------
+__global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restrict__ starts, const double* __restrict__ goals,
+                                               const double* __restrict__ dist, int64_t E, double resolution,
+                                               double max_distance, int mode, double thr, uint8_t* __restrict__ valid,
+                                               double* __restrict__ end, int32_t* __restrict__ n_samples) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t e = blockIdx.x;
+    const int nq = m.n_q;
+    double* lds_q = lds;
+    double* lds_s = lds_q + WAVE * nq;
+    double* lds_fr = lds_s + WAVE * m.shape_rows;
+    const double* s = starts + e * nq;
+    const double* g = goals + e * nq;
+    double d;
+    if (dist != nullptr) d = dist[e];
+    else {
+        double acc = 0.0;
+        for (int i = 0; i < nq; ++i) { const double df = g[i] - s[i]; acc = NBK_FMA(df, df, acc); }
+        d = nbk_sqrt(acc);
+    }
+    if (!(d > 1.1920928955078125e-07)) {   // float32 eps: the reference returns None
+        if (lane == 0) { valid[e] = 0; if (n_samples) n_samples[e] = 0; }
+        if (end != nullptr && lane < nq) end[e * nq + lane] = __builtin_nan("");
+        return;
+    }
+    const double Tf = (mode == NBK_STEER && d > max_distance) ? max_distance / d : 1.0;
+    const double step = resolution / d;
+    const double lenf = __builtin_ceil(Tf / step);
+    const int64_t n = lenf > 0.0 ? (int64_t)lenf : 0;     // len(arange(0, Tf, step)); samples = n + 1
+    bool ok = true;
+    for (int64_t c0 = 0; c0 <= n && ok; c0 += WAVE) {
+        const int64_t i = c0 + lane;
+        const bool active = i <= n;
+        const double t = i < n ? (double)i * step : Tf;
+        const double omt = 1.0 - t;
+        for (int j = 0; j < nq; ++j) {
+            const double a = omt * s[j];
+            const double bb = t * g[j];
+            lds_q[j * WAVE + lane] = a + bb;
+        }
+        sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
+        const bool hit = lane_collides(m, lds_s, lane, thr, active);
+        if (__builtin_amdgcn_ballot_w64(hit && active) != 0ull) ok = false;
+    }
+    if (lane == 0) { valid[e] = ok ? 1 : 0; if (n_samples) n_samples[e] = (int32_t)(n + 1); }
+    if (end != nullptr && lane < nq) {
+        if (mode == NBK_CONNECT) end[e * nq + lane] = g[lane];
+        else {
+            const double omt = 1.0 - Tf;
+            const double a = omt * s[lane];
+            const double bb = Tf * g[lane];
+            end[e * nq + lane] = a + bb;
+        }
+    }
+}
+
+__global__ void k_selftest(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* so, double* co,
+                           double* sq, double* dv) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s, c;
+    nbk_sincos(a[i], s, c);
+    so[i] = s; co[i] = c;
+    sq[i] = nbk_sqrt(a[i]);
+    dv[i] = a[i] / b[i];
+}
+
+// ---- host side --------------------------------------------------------------------------------------
+struct Blob {
+    std::vector<unsigned char> bytes;
+    size_t add(const void* p, size_t n) {
+        size_t off = (bytes.size() + 15) & ~size_t(15);
+        bytes.resize(off + n);
+        if (n) memcpy(bytes.data() + off, p, n);
+        return off;
+    }
+};
+
+static void core_params(int type, const double* param, int& kind, double* cc) {
+    cc[0] = cc[1] = cc[2] = cc[3] = cc[4] = 0.0;
+    switch (type) {
+        case NBK_SPHERE: kind = K_POINT; cc[4] = param[0]; break;
+        case NBK_CAPSULE: kind = K_SEG; cc[4] = param[0]; cc[0] = param[1]; break;
+        case NBK_BOX:
+            kind = K_BOX; cc[4] = param[3];
+            cc[0] = param[0] - param[3]; cc[1] = param[1] - param[3]; cc[2] = param[2] - param[3];
+            break;
+        case NBK_CYLINDER: kind = K_CYL; cc[4] = param[3]; cc[3] = param[0] - param[3]; cc[0] = param[1] - param[3]; break;
+        default: kind = K_PLANE; break;
+    }
+}
+
+static int host_core_rows(int kind) { return kind == K_POINT ? 3 : (kind == K_BOX ? 12 : 6); }
+
+}  // namespace nbk
+
+using namespace nbk;
+
+extern "C" {
+
+int32_t nbk_abi_version(void) { return NBK_ABI_VERSION; }
+
+const char* nbk_status_string(int32_t st) {
+    switch (st) {
+        case NBK_OK: return "ok";
+        case NBK_ERR_INVALID: return "invalid argument";
+        case NBK_ERR_NO_DEVICE: return "no HIP device available";
+        case NBK_ERR_HIP: return "HIP runtime error";
+        case NBK_ERR_UNSUPPORTED: return "descriptor exceeds a compiled-in limit";
+        case NBK_ERR_ALLOC: return "allocation failed";
+        default: return "unknown status";
+    }
+}
+
+const char* nbk_last_error(void) { return g_err; }
+
+int32_t nbk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
+    if (d == nullptr || out == nullptr) return NBK_ERR_INVALID;
+    *out = nullptr;
+    if (nbk_device_count() <= 0) return NBK_ERR_NO_DEVICE;
+    const int J = d->n_joints, S = d->n_rshapes, W = d->n_wshapes, P = d->n_pairs;
+    if (d->n_q < 0 || J < 0 || S < 0 || W < 0 || P < 0) return NBK_ERR_INVALID;
+    if (J > NBK_MAX_JOINTS || d->n_q > NBK_MAX_DOF) return NBK_ERR_UNSUPPORTED;
+    for (int k = 0; k < J; ++k) {
+        if (d->joint_parent[k] >= k || d->joint_parent[k] < -1) return NBK_ERR_INVALID;   // parents first
+        if (d->joint_qidx[k] < 0 || d->joint_qidx[k] >= d->n_q) return NBK_ERR_INVALID;
+        if (d->joint_type[k] != NBK_REVOLUTE && d->joint_type[k] != NBK_PRISMATIC) return NBK_ERR_INVALID;
+    }
+    for (int s = 0; s < S; ++s) {
+        if (d->rshape_frame[s] < -1 || d->rshape_frame[s] >= J) return NBK_ERR_INVALID;
+        if (d->rshape_type[s] < NBK_SPHERE || d->rshape_type[s] > NBK_CYLINDER) return NBK_ERR_INVALID;
+    }
+    for (int w = 0; w < W; ++w)
+        if (d->wshape_type[w] < NBK_SPHERE || d->wshape_type[w] > NBK_PLANE) return NBK_ERR_INVALID;
+    for (int p = 0; p < P; ++p) {
+        if (d->pair_a[p] < 0 || d->pair_a[p] >= S) return NBK_ERR_INVALID;
+        if (d->pair_b[p] < 0 || d->pair_b[p] >= S + W) return NBK_ERR_INVALID;
+    }
+    // frame load/save plan: a frame stays in registers when its child is the next joint
+    std::vector<int> load(J), save(J, -1);
+    int slots = 0;
+    for (int k = 0; k < J; ++k) {
+        const int par = d->joint_parent[k];
+        if (par == k - 1) load[k] = (par < 0) ? -1 : -2;
+        else if (par < 0) load[k] = -1;
+        else {
+            if (save[par] < 0) save[par] = slots++;
+            load[k] = save[par];
+        }
+    }
+    // robot shapes in frame order
+    std::vector<int> order;
+    std::vector<int> begin(J + 2, 0);
+    for (int f = -1; f < J; ++f) {
+        begin[f + 1] = (int)order.size();
+        for (int s = 0; s < S; ++s) if (d->rshape_frame[s] == f) order.push_back(s);
+    }
+    begin[J + 1] = (int)order.size();
+    std::vector<int> new_index(S);
+    std::vector<int> rs_kind(S), rs_row(S);
+    std::vector<double> rs_local(12 * (size_t)S), rs_core(5 * (size_t)S);
+    int rows = 0;
+    for (int i = 0; i < S; ++i) {
+        const int s = order[i];
+        new_index[s] = i;
+        int kind;
+        core_params(d->rshape_type[s], d->rshape_param + 4 * s, kind, &rs_core[5 * i]);
+        rs_kind[i] = kind;
+        rs_row[i] = rows;
+        rows += host_core_rows(kind);
+        memcpy(&rs_local[12 * i], d->rshape_local + 12 * s, 12 * sizeof(double));
+    }
+    std::vector<int> ws_kind(W);
+    std::vector<double> ws_core(17 * (size_t)W);
+    for (int w = 0; w < W; ++w) {
+        double cc[5];
+        int kind;
+        core_params(d->wshape_type[w], d->wshape_param + 4 * w, kind, cc);
+        ws_kind[w] = kind;
+        const double* T = d->wshape_pose + 12 * w;
+        double* o = &ws_core[17 * w];
+        o[0] = T[3]; o[1] = T[7]; o[2] = T[11];
+        for (int j = 0; j < 3; ++j) { o[3 + 3 * j] = T[j]; o[4 + 3 * j] = T[4 + j]; o[5 + 3 * j] = T[8 + j]; }
+        if (kind == K_PLANE) { o[9] = d->wshape_param[4 * w]; o[10] = d->wshape_param[4 * w + 1]; o[11] = d->wshape_param[4 * w + 2]; }
+        o[12] = cc[0]; o[13] = cc[1]; o[14] = cc[2]; o[15] = cc[3]; o[16] = cc[4];
+    }
+    std::vector<int> pa(P), pb(P), pu(P);
+    for (int p = 0; p < P; ++p) {
+        pa[p] = new_index[d->pair_a[p]];
+        pb[p] = d->pair_b[p] < S ? new_index[d->pair_b[p]] : d->pair_b[p];
+        pu[p] = p;
+    }
+    // LDS budget: q rows + shape rows + saved frames, 512 B each; the raw q slab reuses the shape area
+    const size_t lds_bytes = (size_t)(d->n_q + (rows > d->n_q ? rows : d->n_q) + 12 * slots) * 64 * sizeof(double);
+    if (lds_bytes > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+
+    Blob B;
+    nbk_model* M = new nbk_model();
+    memset(&M->d, 0, sizeof(M->d));
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu; } o;
+    o.jt = B.add(d->joint_type, sizeof(int) * J);
+    o.jq = B.add(d->joint_qidx, sizeof(int) * J);
+    o.jl = B.add(load.data(), sizeof(int) * J);
+    o.js = B.add(save.data(), sizeof(int) * J);
+    o.jb = B.add(begin.data(), sizeof(int) * (J + 2));
+    o.jr = B.add(d->joint_rot, sizeof(double) * 27 * J);
+    o.jtr = B.add(d->joint_trans, sizeof(double) * 3 * J);
+    o.jsl = B.add(d->joint_slide, sizeof(double) * 3 * J);
+    o.jax = B.add(d->joint_axis, sizeof(double) * 3 * J);
+    o.bp = B.add(d->base_pose, sizeof(double) * 12);
+    o.rk = B.add(rs_kind.data(), sizeof(int) * S);
+    o.rr = B.add(rs_row.data(), sizeof(int) * S);
+    o.rl = B.add(rs_local.data(), sizeof(double) * 12 * S);
+    o.rc = B.add(rs_core.data(), sizeof(double) * 5 * S);
+    o.wk = B.add(ws_kind.data(), sizeof(int) * W);
+    o.wc = B.add(ws_core.data(), sizeof(double) * 17 * W);
+    o.pa = B.add(pa.data(), sizeof(int) * P);
+    o.pb = B.add(pb.data(), sizeof(int) * P);
+    o.pu = B.add(pu.data(), sizeof(int) * P);
+    B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
+
+    void* dev = nullptr;
+    hipError_t e = hipMalloc(&dev, B.bytes.size());
+    if (e != hipSuccess) { delete M; hip_fail(e, "hipMalloc(model)"); return NBK_ERR_ALLOC; }
+    e = hipMemcpy(dev, B.bytes.data(), B.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(dev); delete M; return hip_fail(e, "hipMemcpy(model)"); }
+    const char* base = static_cast<const char*>(dev);
+    DevModel& m = M->d;
+    m.n_q = d->n_q; m.n_joints = J; m.n_rshapes = S; m.n_wshapes = W; m.n_pairs = P;
+    m.shape_rows = rows > d->n_q ? rows : d->n_q;
+    m.frame_slots = slots;
+    m.joint_type = reinterpret_cast<const int*>(base + o.jt);
+    m.joint_qidx = reinterpret_cast<const int*>(base + o.jq);
+    m.joint_load = reinterpret_cast<const int*>(base + o.jl);
+    m.joint_save = reinterpret_cast<const int*>(base + o.js);
+    m.joint_shape_begin = reinterpret_cast<const int*>(base + o.jb);
+    m.joint_rot = reinterpret_cast<const double*>(base + o.jr);
+    m.joint_trans = reinterpret_cast<const double*>(base + o.jtr);
+    m.joint_slide = reinterpret_cast<const double*>(base + o.jsl);
+    m.joint_axis = reinterpret_cast<const double*>(base + o.jax);
+    m.base_pose = reinterpret_cast<const double*>(base + o.bp);
+    m.rs_kind = reinterpret_cast<const int*>(base + o.rk);
+    m.rs_row = reinterpret_cast<const int*>(base + o.rr);
+    m.rs_local = reinterpret_cast<const double*>(base + o.rl);
+    m.rs_core = reinterpret_cast<const double*>(base + o.rc);
+    m.ws_kind = reinterpret_cast<const int*>(base + o.wk);
+    m.ws_core = reinterpret_cast<const double*>(base + o.wc);
+    m.pair_a = reinterpret_cast<const int*>(base + o.pa);
+    m.pair_b = reinterpret_cast<const int*>(base + o.pb);
+    m.pair_user = reinterpret_cast<const int*>(base + o.pu);
+    M->blob = dev;
+    M->blob_bytes = B.bytes.size();
+    M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
+    (void)hipGetDevice(&M->device);
+    *out = M;
+    return NBK_OK;
+}
+
+void nbk_model_destroy(nbk_model* m) {
+    if (m == nullptr) return;
+    if (m->blob) (void)hipFree(m->blob);
+    delete m;
+}
+
+int32_t nbk_model_num_pairs(const nbk_model* m) { return m ? m->n_pairs : NBK_ERR_INVALID; }
+
+static int make_path(const nbk_model* m, const int32_t* path, int32_t path_len, const double* local, PathArg& pa) {
+    if (path_len < 0 || path_len > NBK_MAX_JOINTS || (path_len > 0 && path == nullptr) || local == nullptr) return NBK_ERR_INVALID;
+    pa.len = path_len;
+    for (int i = 0; i < path_len; ++i) {
+        if (path[i] < 0 || path[i] >= m->n_joints) return NBK_ERR_INVALID;
+        pa.idx[i] = path[i];
+    }
+    for (int i = path_len; i < NBK_MAX_JOINTS; ++i) pa.idx[i] = 0;
+    memcpy(pa.local, local, sizeof(double) * 12);
+    return NBK_OK;
+}
+
+static inline unsigned blocks_for(int64_t B) { return (unsigned)((B + WAVE - 1) / WAVE); }
+
+int32_t nbk_fk_batch(const nbk_model* m, const double* q, int64_t B, const int32_t* path, int32_t path_len,
+                     const double* local, const double* local_pose, double* T_out, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || T_out == nullptr))) return NBK_ERR_INVALID;
+    PathArg pa;
+    const int st = make_path(m, path, path_len, local, pa);
+    if (st != NBK_OK) return st;
+    if (B == 0) return NBK_OK;
+    const size_t lds = sizeof(double) * WAVE * (2 * (size_t)m->n_q + 17);
+    hipLaunchKernelGGL(k_fk, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, local_pose, T_out);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const int32_t* path, int32_t path_len,
+                           const double* local, int32_t mode, const double* pose, double* J_out, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || J_out == nullptr))) return NBK_ERR_INVALID;
+    if (mode < 0 || mode > 2 || (mode != 0 && pose == nullptr && B > 0)) return NBK_ERR_INVALID;
+    PathArg pa;
+    const int st = make_path(m, path, path_len, local, pa);
+    if (st != NBK_OK) return st;
+    if (B == 0) return NBK_OK;
+    const int ncol = 6 * m->n_q;
+    const int stride = ncol + 1 + ((ncol + 1) & 1 ? 0 : 1);
+    const size_t lds = sizeof(double) * WAVE * (2 * (size_t)m->n_q + 6 * (size_t)path_len + (size_t)stride);
+    if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_jacobian, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, mode, pose, J_out);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+static inline size_t collide_lds(const nbk_model* m) {
+    return sizeof(double) * WAVE * ((size_t)m->d.n_q + (size_t)m->d.shape_rows + 12 * (size_t)m->d.frame_slots);
+}
+
+int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+                           uint8_t* mask_bytes, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && q == nullptr) || (mask_bits == nullptr && mask_bytes == nullptr)) return NBK_ERR_INVALID;
+    if (B == 0) return NBK_OK;
+    hipLaunchKernelGGL(k_validity, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, threshold,
+                       mask_bits, mask_bytes);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || min_dist == nullptr))) return NBK_ERR_INVALID;
+    if (B == 0) return NBK_OK;
+    hipLaunchKernelGGL(k_distances<0>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, min_dist,
+                       argmin, (double*)nullptr);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr))) return NBK_ERR_INVALID;
+    if (B == 0 || m->n_pairs == 0) return NBK_OK;
+    if (witness != nullptr)
+        hipLaunchKernelGGL(k_distances<2>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
+                           (int32_t*)nullptr, witness);
+    else
+        hipLaunchKernelGGL(k_distances<1>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
+                           (int32_t*)nullptr, (double*)nullptr);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const double* goals, const double* dist, int64_t E,
+                                double resolution, double max_distance, int32_t mode, double threshold, uint8_t* valid,
+                                double* end, int32_t* n_samples, void* stream) {
+    if (m == nullptr || E < 0 || (E > 0 && (starts == nullptr || goals == nullptr || valid == nullptr))) return NBK_ERR_INVALID;
+    if (!(resolution > 0.0) || !(max_distance > 0.0) || (mode != NBK_CONNECT && mode != NBK_STEER)) return NBK_ERR_INVALID;
+    if (E == 0) return NBK_OK;
+    if (E > 0x7fffffffLL) return NBK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_edges, dim3((unsigned)E), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, starts, goals, dist, E,
+                       resolution, max_distance, mode, threshold, valid, end, n_samples);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_selftest_math(const double* a, const double* b, int64_t n, double* sin_out, double* cos_out, double* sqrt_out,
+                          double* div_out, void* stream) {
+    if (n < 0 || (n > 0 && (!a || !b || !sin_out || !cos_out || !sqrt_out || !div_out))) return NBK_ERR_INVALID;
+    if (n == 0) return NBK_OK;
+    hipLaunchKernelGGL(k_selftest, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, sin_out, cos_out,
+                       sqrt_out, div_out);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_fk_batch_host(const nbk_model* m, const double* q, int64_t B, const int32_t* path, int32_t path_len,
+                          const double* local, double* T_out) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || T_out == nullptr))) return NBK_ERR_INVALID;
+    if (B == 0) return NBK_OK;
+    double *dq = nullptr, *dT = nullptr;
+    NBK_HIP(hipMalloc((void**)&dq, sizeof(double) * B * m->n_q));
+    hipError_t e = hipMalloc((void**)&dT, sizeof(double) * B * 16);
+    if (e != hipSuccess) { (void)hipFree(dq); return hip_fail(e, "hipMalloc"); }
+    int st = NBK_OK;
+    e = hipMemcpy(dq, q, sizeof(double) * B * m->n_q, hipMemcpyHostToDevice);
+    if (e != hipSuccess) st = hip_fail(e, "hipMemcpy H2D");
+    if (st == NBK_OK) st = nbk_fk_batch(m, dq, B, path, path_len, local, nullptr, dT, nullptr);
+    if (st == NBK_OK) { e = hipMemcpy(T_out, dT, sizeof(double) * B * 16, hipMemcpyDeviceToHost); if (e != hipSuccess) st = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(dq); (void)hipFree(dT);
+    return st;
+}
+
+int32_t nbk_validity_batch_host(const nbk_model* m, const double* q, int64_t B, double threshold, uint8_t* mask_bytes) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || mask_bytes == nullptr))) return NBK_ERR_INVALID;
+    if (B == 0) return NBK_OK;
+    double* dq = nullptr;
+    uint8_t* dm = nullptr;
+    NBK_HIP(hipMalloc((void**)&dq, sizeof(double) * B * m->n_q));
+    hipError_t e = hipMalloc((void**)&dm, (size_t)B);
+    if (e != hipSuccess) { (void)hipFree(dq); return hip_fail(e, "hipMalloc"); }
+    int st = NBK_OK;
+    e = hipMemcpy(dq, q, sizeof(double) * B * m->n_q, hipMemcpyHostToDevice);
+    if (e != hipSuccess) st = hip_fail(e, "hipMemcpy H2D");
+    if (st == NBK_OK) st = nbk_validity_batch(m, dq, B, threshold, nullptr, dm, nullptr);
+    if (st == NBK_OK) { e = hipMemcpy(mask_bytes, dm, (size_t)B, hipMemcpyDeviceToHost); if (e != hipSuccess) st = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(dq); (void)hipFree(dm);
+    return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,707 @@
+// nbk_device.hpp -- per-lane device math for the gfx950 kernels: transforms, sincos, convex cores,
+// support mapping, GJK, overlap depth, closed-form point/segment distances.
+//
+// One configuration per lane; everything here is straight-line float64 on VGPRs.  Shape kinds and all
+// model constants are wave-uniform, so every `switch (kind)` below is a scalar branch (no divergence);
+// the only divergent control flow is the GJK iteration count and its Voronoi-region walk.
+//
+// Arithmetic contract: compiled with -ffp-contract=off, every fused multiply-add is written
+// as NBK_FMA, sqrt/divide are the IEEE correctly-rounded ones, and sin/cos are nbk_sincos below -- so the
+// results are a pure function of the written operation order and can be checked bit-for-bit on a CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NBK_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define NBK_DEV __device__ __forceinline__
+#define NBK_INF __builtin_huge_val()
+
+namespace nbk {
+
+enum { K_POINT = 0, K_SEG = 1, K_BOX = 2, K_CYL = 3, K_PLANE = 4 };
+
+// ---- small vectors ---------------------------------------------------------------------------
+NBK_DEV double dot3(const double* a, const double* b) { return NBK_FMA(a[2], b[2], NBK_FMA(a[1], b[1], a[0] * b[0])); }
+NBK_DEV void sub3(const double* a, const double* b, double* o) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+NBK_DEV void cross3(const double* a, const double* b, double* o) {
+    o[0] = NBK_FMA(a[1], b[2], -(a[2] * b[1]));
+    o[1] = NBK_FMA(a[2], b[0], -(a[0] * b[2]));
+    o[2] = NBK_FMA(a[0], b[1], -(a[1] * b[0]));
+}
+// o = a + s*b   (o may alias a)
+NBK_DEV void axpy3(double s, const double* b, const double* a, double* o) {
+    const double o0 = NBK_FMA(s, b[0], a[0]), o1 = NBK_FMA(s, b[1], a[1]), o2 = NBK_FMA(s, b[2], a[2]);
+    o[0] = o0; o[1] = o1; o[2] = o2;
+}
+NBK_DEV void copy3(const double* a, double* o) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+NBK_DEV double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+NBK_DEV double nbk_sqrt(double x) { return __builtin_sqrt(x); }
+
+// ---- 3x4 rigid transforms ----------------------------------------------------------------------
+struct Xf { double R[9]; double t[3]; };
+
+// o = a * (Rb, tb); Rb/tb may be wave-uniform constants
+NBK_DEV void xf_mul(const Xf& a, const double* Rb, const double* tb, Xf& o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a0 = a.R[3 * i], a1 = a.R[3 * i + 1], a2 = a.R[3 * i + 2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o.R[3 * i + j] = NBK_FMA(a2, Rb[6 + j], NBK_FMA(a1, Rb[3 + j], a0 * Rb[j]));
+        o.t[i] = NBK_FMA(a2, tb[2], NBK_FMA(a1, tb[1], NBK_FMA(a0, tb[0], a.t[i])));
+    }
+}
+// only column j of the rotation of a*(Rb,.)
+NBK_DEV void xf_mul_col(const Xf& a, const double* Rb, int j, double* col) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        col[i] = NBK_FMA(a.R[3 * i + 2], Rb[6 + j], NBK_FMA(a.R[3 * i + 1], Rb[3 + j], a.R[3 * i] * Rb[j]));
+}
+NBK_DEV void xf_mul_pos(const Xf& a, const double* tb, double* p) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        p[i] = NBK_FMA(a.R[3 * i + 2], tb[2], NBK_FMA(a.R[3 * i + 1], tb[1], NBK_FMA(a.R[3 * i], tb[0], a.t[i])));
+}
+NBK_DEV void xf_from12(const double* p, Xf& x) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x.R[3 * i] = p[4 * i]; x.R[3 * i + 1] = p[4 * i + 1]; x.R[3 * i + 2] = p[4 * i + 2];
+        x.t[i] = p[4 * i + 3];
+    }
+}
+
+// ---- sincos: Cody-Waite reduction by pi/2 + minimax kernels on [-pi/4, pi/4] --------------------
+NBK_DEV void nbk_sincos(double x, double& s, double& c) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00, PIO2_2 = 6.07710050630396597660e-11,
+                 PIO2_3 = 2.02226624871116645580e-21;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    if (!(__builtin_fabs(x) < 2147483648.0)) { s = __builtin_nan(""); c = s; return; }
+    const double k = __builtin_rint(x * TWO_OVER_PI);
+    double r = NBK_FMA(-k, PIO2_1, x);
+    r = NBK_FMA(-k, PIO2_2, r);
+    r = NBK_FMA(-k, PIO2_3, r);
+    const double z = r * r;
+    double ps = NBK_FMA(z, S6, S5);
+    ps = NBK_FMA(z, ps, S4); ps = NBK_FMA(z, ps, S3); ps = NBK_FMA(z, ps, S2); ps = NBK_FMA(z, ps, S1);
+    const double sr = NBK_FMA(r * z, ps, r);
+    double pc = NBK_FMA(z, C6, C5);
+    pc = NBK_FMA(z, pc, C4); pc = NBK_FMA(z, pc, C3); pc = NBK_FMA(z, pc, C2); pc = NBK_FMA(z, pc, C1);
+    const double cr = NBK_FMA(z * z, pc, NBK_FMA(-0.5, z, 1.0));
+    const int n = (int)((long long)k & 3LL);
+    const bool swap = (n & 1) != 0;
+    const double a = swap ? cr : sr;       // |sin|
+    const double b = swap ? sr : cr;       // |cos|
+    s = (n & 2) ? -a : a;
+    c = ((n + 1) & 2) ? -b : b;
+}
+
+// ---- convex cores ------------------------------------------------------------------------------
+// shape = core (+) ball(margin):  sphere = point, capsule = segment, box, cylinder (axis = local z)
+struct Core {
+    int kind;            // wave-uniform
+    double c[3];
+    double ax[3][3];     // ax[j] = world direction of local axis j (box: all three; seg/cyl: ax[2])
+    double h[3];         // uniform: seg/cyl h[0] = half length; box half extents
+    double rad;          // uniform: cylinder radius
+    double margin;       // uniform
+};
+
+NBK_DEV void core_support(const Core& s, const double* d, double* o) {
+    switch (s.kind) {
+        case K_POINT: copy3(s.c, o); break;
+        case K_SEG: {
+            const double du = dot3(d, s.ax[2]);
+            const double sg = du >= 0.0 ? s.h[0] : -s.h[0];
+            axpy3(sg, s.ax[2], s.c, o);
+        } break;
+        case K_CYL: {
+            const double du = dot3(d, s.ax[2]);
+            const double sg = du >= 0.0 ? s.h[0] : -s.h[0];
+            double w[3];
+            axpy3(-du, s.ax[2], d, w);
+            axpy3(-dot3(w, s.ax[2]), s.ax[2], w, w);   // second Gram-Schmidt pass (d almost axial: see oracle)
+            const double ww = dot3(w, w);
+            axpy3(sg, s.ax[2], s.c, o);
+            if (ww > 0.0) {
+                const double k = s.rad / nbk_sqrt(ww);
+                axpy3(k, w, o, o);
+            }
+        } break;
+        default: {
+            copy3(s.c, o);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double dj = dot3(d, s.ax[j]);
+                const double sj = dj >= 0.0 ? s.h[j] : -s.h[j];
+                axpy3(sj, s.ax[j], o, o);
+            }
+        } break;
+    }
+}
+
+NBK_DEV double core_halfwidth(const Core& s, const double* n) {
+    switch (s.kind) {
+        case K_POINT: return 0.0;
+        case K_SEG: return s.h[0] * __builtin_fabs(dot3(n, s.ax[2]));
+        case K_CYL: {
+            const double nu = dot3(n, s.ax[2]);
+            const double r2 = NBK_FMA(-nu, nu, 1.0);
+            return NBK_FMA(s.rad, nbk_sqrt(r2 > 0.0 ? r2 : 0.0), s.h[0] * __builtin_fabs(nu));
+        }
+        default:
+            return NBK_FMA(s.h[2], __builtin_fabs(dot3(n, s.ax[2])),
+                           NBK_FMA(s.h[1], __builtin_fabs(dot3(n, s.ax[1])), s.h[0] * __builtin_fabs(dot3(n, s.ax[0]))));
+    }
+}
+
+// ---- GJK ---------------------------------------------------------------------------------------
+// The simplex lives in registers: four slots, moved with selects (no dynamically indexed arrays, so
+// nothing goes to scratch).  WIT carries the support points of A and B for witness recovery.
+constexpr int GJK_MAXIT = 64;
+constexpr double GJK_EPS_REL = 1e-10;
+constexpr double GJK_TINY2 = 1e-30;
+
+template <bool WIT>
+struct Simplex {
+    double y[4][3];
+    double a[WIT ? 4 : 1][3];
+    double b[WIT ? 4 : 1][3];
+    double lam[4];
+    int n;
+};
+
+// result of a closest-point query on a sub-simplex: up to 3 kept slots (indices into the CURRENT simplex)
+struct Closest { double v[3]; int idx[3]; double lam[3]; int n; };
+
+template <bool WIT>
+NBK_DEV void sx_get(const Simplex<WIT>& s, int i, double* y) {
+    // select chain (i is lane-varying)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) y[c] = i == 0 ? s.y[0][c] : (i == 1 ? s.y[1][c] : (i == 2 ? s.y[2][c] : s.y[3][c]));
+}
+
+NBK_DEV void closest_seg(const double* A, const double* Bp, int i0, int i1, Closest& r) {
+    double ab[3];
+    sub3(Bp, A, ab);
+    const double t = -dot3(A, ab);
+    if (t <= 0.0) { copy3(A, r.v); r.idx[0] = i0; r.lam[0] = 1.0; r.n = 1; return; }
+    const double den = dot3(ab, ab);
+    if (t >= den) { copy3(Bp, r.v); r.idx[0] = i1; r.lam[0] = 1.0; r.n = 1; return; }
+    const double tt = t / den;
+    axpy3(tt, ab, A, r.v);
+    r.idx[0] = i0; r.idx[1] = i1; r.lam[0] = 1.0 - tt; r.lam[1] = tt; r.n = 2;
+}
+
+NBK_DEV void closest_tri(const double* A, const double* Bp, const double* Cp, int i0, int i1, int i2, Closest& r) {
+    double ab[3], ac[3];
+    sub3(Bp, A, ab); sub3(Cp, A, ac);
+    const double d1 = -dot3(ab, A), d2 = -dot3(ac, A);
+    if (d1 <= 0.0 && d2 <= 0.0) { copy3(A, r.v); r.idx[0] = i0; r.lam[0] = 1.0; r.n = 1; return; }
+    const double d3 = -dot3(ab, Bp), d4 = -dot3(ac, Bp);
+    if (d3 >= 0.0 && d4 <= d3) { copy3(Bp, r.v); r.idx[0] = i1; r.lam[0] = 1.0; r.n = 1; return; }
+    const double vc = NBK_FMA(d1, d4, -(d3 * d2));
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        const double t = d1 / (d1 - d3);
+        axpy3(t, ab, A, r.v);
+        r.idx[0] = i0; r.idx[1] = i1; r.lam[0] = 1.0 - t; r.lam[1] = t; r.n = 2;
+        return;
+    }
+    const double d5 = -dot3(ab, Cp), d6 = -dot3(ac, Cp);
+    if (d6 >= 0.0 && d5 <= d6) { copy3(Cp, r.v); r.idx[0] = i2; r.lam[0] = 1.0; r.n = 1; return; }
+    const double vb = NBK_FMA(d5, d2, -(d1 * d6));
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+        const double t = d2 / (d2 - d6);
+        axpy3(t, ac, A, r.v);
+        r.idx[0] = i0; r.idx[1] = i2; r.lam[0] = 1.0 - t; r.lam[1] = t; r.n = 2;
+        return;
+    }
+    const double va = NBK_FMA(d3, d6, -(d5 * d4));
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double t = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        double bc[3];
+        sub3(Cp, Bp, bc);
+        axpy3(t, bc, Bp, r.v);
+        r.idx[0] = i1; r.idx[1] = i2; r.lam[0] = 1.0 - t; r.lam[1] = t; r.n = 2;
+        return;
+    }
+    const double den = 1.0 / (va + vb + vc);
+    const double tv = vb * den, tw = vc * den;
+    double tmp[3];
+    axpy3(tv, ab, A, tmp);
+    axpy3(tw, ac, tmp, r.v);
+    r.idx[0] = i0; r.idx[1] = i1; r.idx[2] = i2;
+    r.lam[0] = (1.0 - tv) - tw; r.lam[1] = tv; r.lam[2] = tw; r.n = 3;
+}
+
+NBK_DEV bool outside_face(const double* a, const double* b, const double* c, const double* d) {
+    double ab[3], ac[3], ad[3], n[3];
+    sub3(b, a, ab); sub3(c, a, ac); sub3(d, a, ad);
+    cross3(ab, ac, n);
+    const double sp = -dot3(a, n);
+    const double sd = dot3(ad, n);
+    return (sp * sd < 0.0) || (sd == 0.0);
+}
+
+// keep the slots r.idx[0..n) in that order
+template <bool WIT>
+NBK_DEV void sx_keep(Simplex<WIT>& s, const Closest& r) {
+    double ny[3][3], na[3][3], nb[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = r.idx[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            ny[i][c] = k == 0 ? s.y[0][c] : (k == 1 ? s.y[1][c] : (k == 2 ? s.y[2][c] : s.y[3][c]));
+            if constexpr (WIT) {
+                na[i][c] = k == 0 ? s.a[0][c] : (k == 1 ? s.a[1][c] : (k == 2 ? s.a[2][c] : s.a[3][c]));
+                nb[i][c] = k == 0 ? s.b[0][c] : (k == 1 ? s.b[1][c] : (k == 2 ? s.b[2][c] : s.b[3][c]));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < r.n) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s.y[i][c] = ny[i][c];
+                if constexpr (WIT) { s.a[i][c] = na[i][c]; s.b[i][c] = nb[i][c]; }
+            }
+            s.lam[i] = r.lam[i];
+        }
+    }
+    s.n = r.n;
+}
+
+// one simplex update shared by the distance and the predicate loops: place w in slot n, find the closest
+// point of the enlarged simplex to the origin and shrink to its support.
+// returns 0 = advanced (v, vv_prev updated), 1 = origin enclosed / touching, 2 = no progress.
+// On 1 and 2 the simplex is left as it was (slots 0..n-1 and their lambdas untouched).
+template <bool WIT>
+NBK_DEV int gjk_advance(Simplex<WIT>& sx, const double* w, const double* sa, const double* sb, double* v, double& vv_prev) {
+    const int k = sx.n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i == k) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                sx.y[i][c] = w[c];
+                if constexpr (WIT) { sx.a[i][c] = sa[c]; sx.b[i][c] = sb[c]; }
+            }
+        }
+    }
+    Closest r;
+    r.n = 0; r.idx[0] = r.idx[1] = r.idx[2] = 0; r.lam[0] = r.lam[1] = r.lam[2] = 0.0;
+    r.v[0] = r.v[1] = r.v[2] = 0.0;
+    bool inside = false;
+    if (k == 0) {
+        copy3(sx.y[0], r.v); r.idx[0] = 0; r.lam[0] = 1.0; r.n = 1;
+    } else if (k == 1) {
+        closest_seg(sx.y[0], sx.y[1], 0, 1, r);
+    } else if (k == 2) {
+        closest_tri(sx.y[0], sx.y[1], sx.y[2], 0, 1, 2, r);
+    } else {
+        // faces (0,1,2|3) (0,2,3|1) (0,3,1|2) (1,3,2|0): best of the faces the origin is outside of
+        double best = NBK_INF;
+        bool any = false;
+        Closest cr;
+        if (outside_face(sx.y[0], sx.y[1], sx.y[2], sx.y[3])) {
+            any = true;
+            closest_tri(sx.y[0], sx.y[1], sx.y[2], 0, 1, 2, cr);
+            const double dd = dot3(cr.v, cr.v);
+            if (dd < best) { best = dd; r = cr; }
+        }
+        if (outside_face(sx.y[0], sx.y[2], sx.y[3], sx.y[1])) {
+            any = true;
+            closest_tri(sx.y[0], sx.y[2], sx.y[3], 0, 2, 3, cr);
+            const double dd = dot3(cr.v, cr.v);
+            if (dd < best) { best = dd; r = cr; }
+        }
+        if (outside_face(sx.y[0], sx.y[3], sx.y[1], sx.y[2])) {
+            any = true;
+            closest_tri(sx.y[0], sx.y[3], sx.y[1], 0, 3, 1, cr);
+            const double dd = dot3(cr.v, cr.v);
+            if (dd < best) { best = dd; r = cr; }
+        }
+        if (outside_face(sx.y[1], sx.y[3], sx.y[2], sx.y[0])) {
+            any = true;
+            closest_tri(sx.y[1], sx.y[3], sx.y[2], 1, 3, 2, cr);
+            const double dd = dot3(cr.v, cr.v);
+            if (dd < best) { best = dd; r = cr; }
+        }
+        inside = !any;
+    }
+    if (inside) return 1;
+    const double nn = dot3(r.v, r.v);
+    if (nn <= GJK_TINY2) return 1;
+    if (nn >= vv_prev) return 2;
+    sx_keep<WIT>(sx, r);
+    vv_prev = nn;
+    copy3(r.v, v);
+    return 0;
+}
+
+template <bool WIT>
+NBK_DEV void sx_init(Simplex<WIT>& sx) {
+    sx.n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sx.lam[i] = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sx.y[i][c] = 0.0;
+    }
+    if constexpr (WIT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sx.a[i][c] = 0.0; sx.b[i][c] = 0.0; }
+    }
+}
+
+template <bool WIT>
+NBK_DEV bool sx_has(const Simplex<WIT>& sx, const double* w) {
+    bool dup = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < sx.n && sx.y[i][0] == w[0] && sx.y[i][1] == w[1] && sx.y[i][2] == w[2]) dup = true;
+    return dup;
+}
+
+// GJK distance.  returns true when the cores overlap (or touch); otherwise vout = closest vector (B -> A)
+// and, with WIT, pa/pb the witness points.  `sep` = a separating plane has been proven (v.w > 0); after
+// that an "enclosed" verdict can only be breakdown of a degenerate simplex and just ends the iteration.
+// Convergence: |v|^2 - max_k (v_k.w_k)^2/|v_k|^2 <= eps |v|^2 (best lower bound seen so far).
+template <bool WIT>
+NBK_DEV bool gjk_cores(const Core& A, const Core& Bc, double* vout, double* pa, double* pb) {
+    Simplex<WIT> sx;
+    sx_init<WIT>(sx);
+    double v[3];
+    sub3(A.c, Bc.c, v);
+    if (dot3(v, v) == 0.0) { v[0] = 1.0; v[1] = 0.0; v[2] = 0.0; }
+    double vv_prev = NBK_INF, lb2 = 0.0;
+    bool overlap = false, sep = false;
+    for (int it = 0; it < GJK_MAXIT; ++it) {
+        const double nv[3] = {-v[0], -v[1], -v[2]};
+        double sa[3], sb[3], w[3];
+        core_support(A, nv, sa);
+        core_support(Bc, v, sb);
+        sub3(sa, sb, w);
+        const double vv = dot3(v, v);
+        const double vw = dot3(v, w);
+        if (vw > 0.0) {
+            sep = true;
+            const double l2 = (vw * vw) / vv;
+            if (l2 > lb2) lb2 = l2;
+        }
+        if (sx.n > 0 && (vv - lb2) <= GJK_EPS_REL * vv) break;
+        if (sx_has<WIT>(sx, w)) break;
+        const int st = gjk_advance<WIT>(sx, w, sa, sb, v, vv_prev);
+        if (st == 1) { overlap = !sep; break; }
+        if (st == 2) break;
+    }
+    if (overlap) return true;
+    copy3(v, vout);
+    if constexpr (WIT) {
+        pa[0] = pa[1] = pa[2] = 0.0; pb[0] = pb[1] = pb[2] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < sx.n) { axpy3(sx.lam[i], sx.a[i], pa, pa); axpy3(sx.lam[i], sx.b[i], pb, pb); }
+        }
+    }
+    return false;
+}
+
+NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
+
+// GJK predicate: dist(coreA, coreB) < tc ?  Same iteration, but it returns as soon as the support-plane
+// lower bound reaches tc (free) or the simplex point drops below tc (colliding).
+NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
+    Simplex<false> sx;
+    sx_init<false>(sx);
+    double v[3];
+    sub3(A.c, Bc.c, v);
+    if (dot3(v, v) == 0.0) { v[0] = 1.0; v[1] = 0.0; v[2] = 0.0; }
+    double vv_prev = NBK_INF, lb2 = 0.0;
+    const double tc2 = tc * tc;
+    bool sep = false;
+    for (int it = 0; it < GJK_MAXIT; ++it) {
+        const double nv[3] = {-v[0], -v[1], -v[2]};
+        double sa[3], sb[3], w[3];
+        core_support(A, nv, sa);
+        core_support(Bc, v, sb);
+        sub3(sa, sb, w);
+        const double vv = dot3(v, v);
+        const double vw = dot3(v, w);
+        if (vw > 0.0) {
+            sep = true;
+            if (tc <= 0.0) return false;
+            if (vw * vw >= tc2 * vv) return false;
+            const double l2 = (vw * vw) / vv;
+            if (l2 > lb2) lb2 = l2;
+        }
+        if (sx.n > 0 && (vv - lb2) <= GJK_EPS_REL * vv) break;
+        if (sx_has<false>(sx, w)) break;
+        const int st = gjk_advance<false>(sx, w, sa, sb, v, vv_prev);
+        if (st == 1) {
+            if (sep) break;
+            if (tc >= 0.0) return true;
+            double nrm[3];
+            return -overlap_depth(A, Bc, nrm) < tc;
+        }
+        if (st == 2) break;
+        if (tc > 0.0 && vv_prev < tc2) return true;
+    }
+    return nbk_sqrt(dot3(v, v)) < tc;
+}
+
+// ---- overlap depth over the candidate axis family ---------------------------------------------
+NBK_DEV void try_axis(const Core& A, const Core& Bc, const double* delta, const double* n_in, double& best, double* bn) {
+    const double nn = dot3(n_in, n_in);
+    if (!(nn > 1e-24)) return;
+    const double inv = 1.0 / nbk_sqrt(nn);
+    const double n[3] = {n_in[0] * inv, n_in[1] * inv, n_in[2] * inv};
+    const double proj = dot3(n, delta);
+    const double ov = (core_halfwidth(A, n) + core_halfwidth(Bc, n)) - __builtin_fabs(proj);
+    if (ov < best) {
+        best = ov;
+        const double sg = proj >= 0.0 ? 1.0 : -1.0;
+        bn[0] = sg * n[0]; bn[1] = sg * n[1]; bn[2] = sg * n[2];
+    }
+}
+
+NBK_DEV int core_naxes(const Core& s) { return s.kind == K_BOX ? 3 : ((s.kind == K_SEG || s.kind == K_CYL) ? 1 : 0); }
+// axis i of the family of core s: box -> ax[i]; seg/cyl -> ax[2]
+NBK_DEV const double* core_axis(const Core& s, int i) { return s.kind == K_BOX ? s.ax[i] : s.ax[2]; }
+
+NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
+    double delta[3];
+    sub3(A.c, Bc.c, delta);
+    double best = NBK_INF;
+    normal[0] = 1.0; normal[1] = 0.0; normal[2] = 0.0;
+    const int na = core_naxes(A), nb = core_naxes(Bc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) if (i < na) try_axis(A, Bc, delta, core_axis(A, i), best, normal);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (j < nb) try_axis(A, Bc, delta, core_axis(Bc, j), best, normal);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (i < na && j < nb) {
+                double cr[3];
+                cross3(core_axis(A, i), core_axis(Bc, j), cr);
+                try_axis(A, Bc, delta, cr, best, normal);
+            }
+    if (A.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A.ax[2]), A.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
+    if (Bc.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc.ax[2]), Bc.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
+    try_axis(A, Bc, delta, delta, best, normal);
+    if (best == NBK_INF) best = 0.0;
+    return best;
+}
+
+// ---- closed forms for point / segment cores ---------------------------------------------------
+NBK_DEV void seg_seg_closest(const Core& A, const Core& Bc, double* pa, double* pb) {
+    const double ha = A.h[0], hb = Bc.h[0];
+    double r[3];
+    sub3(A.c, Bc.c, r);
+    const double b = dot3(A.ax[2], Bc.ax[2]), c = dot3(A.ax[2], r), f = dot3(Bc.ax[2], r);
+    const double den = NBK_FMA(-b, b, 1.0);
+    double s = 0.0;
+    if (den > 1e-14) s = clampd(NBK_FMA(b, f, -c) / den, -ha, ha);
+    double t = NBK_FMA(b, s, f);
+    if (t < -hb) { t = -hb; s = clampd(NBK_FMA(b, t, -c), -ha, ha); }
+    else if (t > hb) { t = hb; s = clampd(NBK_FMA(b, t, -c), -ha, ha); }
+    axpy3(s, A.ax[2], A.c, pa);
+    axpy3(t, Bc.ax[2], Bc.c, pb);
+}
+
+NBK_DEV void ps_closest(const Core& A, const Core& Bc, double* pa, double* pb) {
+    if (A.kind == K_POINT && Bc.kind == K_POINT) {
+        copy3(A.c, pa); copy3(Bc.c, pb);
+    } else if (A.kind == K_POINT) {
+        double d[3];
+        sub3(A.c, Bc.c, d);
+        const double t = clampd(dot3(d, Bc.ax[2]), -Bc.h[0], Bc.h[0]);
+        copy3(A.c, pa);
+        axpy3(t, Bc.ax[2], Bc.c, pb);
+    } else if (Bc.kind == K_POINT) {
+        double d[3];
+        sub3(Bc.c, A.c, d);
+        const double t = clampd(dot3(d, A.ax[2]), -A.h[0], A.h[0]);
+        axpy3(t, A.ax[2], A.c, pa);
+        copy3(Bc.c, pb);
+    } else {
+        seg_seg_closest(A, Bc, pa, pb);
+    }
+}
+
+// point p against a box / cylinder core: signed core distance, closest surface point, outward normal
+NBK_DEV double point_solid(const double* p, const Core& S, double* cp, double* nrm) {
+    double d[3];
+    sub3(p, S.c, d);
+    if (S.kind == K_BOX) {
+        double x[3], qx[3];
+        bool outside = false;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            x[j] = dot3(d, S.ax[j]);
+            qx[j] = clampd(x[j], -S.h[j], S.h[j]);
+            if (__builtin_fabs(x[j]) > S.h[j]) outside = true;
+        }
+        if (outside) {
+            copy3(S.c, cp);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) axpy3(qx[j], S.ax[j], cp, cp);
+            double e[3];
+            sub3(p, cp, e);
+            const double dist = nbk_sqrt(dot3(e, e));
+            const double inv = 1.0 / dist;
+            nrm[0] = e[0] * inv; nrm[1] = e[1] * inv; nrm[2] = e[2] * inv;
+            return dist;
+        }
+        const double g0 = S.h[0] - __builtin_fabs(x[0]), g1 = S.h[1] - __builtin_fabs(x[1]), g2 = S.h[2] - __builtin_fabs(x[2]);
+        int jm = 0;
+        double best = g0;
+        if (g1 < best) { best = g1; jm = 1; }
+        if (g2 < best) { best = g2; jm = 2; }
+        const double xm = jm == 0 ? x[0] : (jm == 1 ? x[1] : x[2]);
+        const double sg = xm >= 0.0 ? 1.0 : -1.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double a = jm == 0 ? S.ax[0][c] : (jm == 1 ? S.ax[1][c] : S.ax[2][c]);
+            nrm[c] = sg * a;
+        }
+        axpy3(best, nrm, p, cp);
+        return -best;
+    }
+    const double* u = S.ax[2];
+    const double z = dot3(d, u);
+    double w[3];
+    axpy3(-z, u, d, w);
+    const double rho = nbk_sqrt(dot3(w, w));
+    const double dz = __builtin_fabs(z) - S.h[0], dr = rho - S.rad;
+    const double sz = z >= 0.0 ? 1.0 : -1.0;
+    double rdir[3];
+    if (rho > 0.0) { const double inv = 1.0 / rho; rdir[0] = w[0] * inv; rdir[1] = w[1] * inv; rdir[2] = w[2] * inv; }
+    else { copy3(S.ax[0], rdir); }
+    if (dz <= 0.0 && dr <= 0.0) {
+        if (dr > dz) { copy3(rdir, nrm); axpy3(-dr, nrm, p, cp); return dr; }
+        nrm[0] = sz * u[0]; nrm[1] = sz * u[1]; nrm[2] = sz * u[2];
+        axpy3(-dz, nrm, p, cp);
+        return dz;
+    }
+    const double zc = clampd(z, -S.h[0], S.h[0]);
+    const double rc = rho < S.rad ? rho : S.rad;
+    double tmp[3];
+    axpy3(zc, u, S.c, tmp);
+    axpy3(rc, rdir, tmp, cp);
+    double e[3];
+    sub3(p, cp, e);
+    const double dist = nbk_sqrt(dot3(e, e));
+    const double inv = 1.0 / dist;
+    nrm[0] = e[0] * inv; nrm[1] = e[1] * inv; nrm[2] = e[2] * inv;
+    return dist;
+}
+
+// signed distance between two shapes; wit (WIT only) = point on A, point on B, unit normal B -> A
+template <bool WIT>
+NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
+    double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0}, n[3] = {1, 0, 0};
+    double dc;
+    if (Bc.kind == K_PLANE) {
+        const double* nn = Bc.ax[2];
+        double d[3];
+        sub3(A.c, Bc.c, d);
+        const double hc = dot3(d, nn);
+        const double hw = core_halfwidth(A, nn);
+        const double dist = (hc - hw) - A.margin;
+        if constexpr (WIT) {
+            const double neg[3] = {-nn[0], -nn[1], -nn[2]};
+            core_support(A, neg, pa);
+            axpy3(-A.margin, nn, pa, pa);
+            axpy3(-dist, nn, pa, pb);
+            copy3(pa, wit); copy3(pb, wit + 3); copy3(nn, wit + 6);
+        }
+        return dist;
+    }
+    const bool a_ps = (A.kind == K_POINT || A.kind == K_SEG), b_ps = (Bc.kind == K_POINT || Bc.kind == K_SEG);
+    if (a_ps && b_ps) {
+        ps_closest(A, Bc, pa, pb);
+        double e[3];
+        sub3(pa, pb, e);
+        dc = nbk_sqrt(dot3(e, e));
+        if constexpr (WIT) {
+            if (dc > 0.0) { const double inv = 1.0 / dc; n[0] = e[0] * inv; n[1] = e[1] * inv; n[2] = e[2] * inv; }
+            else {
+                double cr[3];
+                cross3(A.ax[2], Bc.ax[2], cr);
+                const double cc = dot3(cr, cr);
+                if (A.kind == K_SEG && Bc.kind == K_SEG && cc > 1e-24) { const double inv = 1.0 / nbk_sqrt(cc); n[0] = cr[0] * inv; n[1] = cr[1] * inv; n[2] = cr[2] * inv; }
+                else { n[0] = 1.0; n[1] = 0.0; n[2] = 0.0; }
+            }
+        }
+    } else if (A.kind == K_POINT) {
+        double nb[3];
+        dc = point_solid(A.c, Bc, pb, nb);
+        copy3(A.c, pa); copy3(nb, n);
+    } else if (Bc.kind == K_POINT) {
+        double na[3];
+        dc = point_solid(Bc.c, A, pa, na);
+        copy3(Bc.c, pb);
+        n[0] = -na[0]; n[1] = -na[1]; n[2] = -na[2];
+    } else {
+        double v[3];
+        const bool ov = gjk_cores<WIT>(A, Bc, v, pa, pb);
+        if (!ov) {
+            // the distance is the norm of GJK's own closest vector; pa/pb only serve as witnesses
+            dc = nbk_sqrt(dot3(v, v));
+            if constexpr (WIT) {
+                const double inv = 1.0 / dc;
+                n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
+            }
+        } else {
+            const double depth = overlap_depth(A, Bc, n);
+            dc = -depth;
+            if constexpr (WIT) {
+                const double neg[3] = {-n[0], -n[1], -n[2]};
+                core_support(A, neg, pa);
+                axpy3(dc, n, pa, pb);
+            }
+        }
+    }
+    const double dist = (dc - A.margin) - Bc.margin;
+    if constexpr (WIT) {
+        double wa[3], wb[3];
+        axpy3(-A.margin, n, pa, wa);
+        axpy3(Bc.margin, n, pb, wb);
+        copy3(wa, wit); copy3(wb, wit + 3); copy3(n, wit + 6);
+    }
+    return dist;
+}
+
+// validity predicate of one pair: signed distance < thr, decided on the core distance against
+// tc = (thr + mA) + mB so that nothing is iterated or rooted once the answer is known.
+NBK_DEV bool cores_collide(const Core& A, const Core& Bc, double thr) {
+    if (Bc.kind == K_PLANE) {
+        double d[3];
+        sub3(A.c, Bc.c, d);
+        return (dot3(d, Bc.ax[2]) - core_halfwidth(A, Bc.ax[2])) < (thr + A.margin);
+    }
+    const double tc = (thr + A.margin) + Bc.margin;
+    const bool a_ps = (A.kind == K_POINT || A.kind == K_SEG), b_ps = (Bc.kind == K_POINT || Bc.kind == K_SEG);
+    if (a_ps && b_ps) {
+        double pa[3], pb[3], e[3];
+        ps_closest(A, Bc, pa, pb);
+        sub3(pa, pb, e);
+        return nbk_sqrt(dot3(e, e)) < tc;
+    }
+    if (A.kind == K_POINT) { double cp[3], nb[3]; return point_solid(A.c, Bc, cp, nb) < tc; }
+    if (Bc.kind == K_POINT) { double cp[3], na[3]; return point_solid(Bc.c, A, cp, na) < tc; }
+    return gjk_collides(A, Bc, tc);
+}
+
+}  // namespace nbk

@@ -1,0 +1,214 @@
+"""Device engine: owns an ``nbk_model`` handle and launches the HIP kernels on torch-managed buffers.
+
+PyTorch is plumbing only (device memory, the current HIP stream); every number is produced by
+libnbk.so.  NumPy inputs are staged to the GPU and results are returned as NumPy; torch CUDA tensors
+stay on the device.  Without a GPU every compute call raises ``NbkError`` -- there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NbkError
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _require_gpu():
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise NbkError("no GPU visible: the numbotics_amd device path has no CPU fallback")
+    return torch
+
+
+class _Staged:
+    """A float64 (B, n) device tensor plus how to hand results back."""
+
+    def __init__(self, x, n_cols, what="q"):
+        torch = _require_gpu()
+        self.numpy = not torch.is_tensor(x)
+        if self.numpy:
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float64)).reshape(-1, n_cols)
+            self.t = torch.from_numpy(a).to("cuda", non_blocking=False)
+        else:
+            if not x.is_cuda:
+                x = x.to("cuda")
+            self.t = x.to(torch.float64).contiguous().reshape(-1, n_cols)
+        self.B = int(self.t.shape[0])
+        self.device = self.t.device
+
+    def out(self, t):
+        return t.cpu().numpy() if self.numpy else t
+
+
+def _host_f64(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a
+
+
+class DeviceModel:
+    """Immutable device descriptor built from a KinematicModel or SceneModel (robots/model.py)."""
+
+    def __init__(self, model):
+        _require_gpu()
+        lib = _lib.load()
+        kin = getattr(model, "kin", model)
+        scene = model if hasattr(model, "kin") else None
+        self.kin, self.scene = kin, scene
+        keep = []
+
+        def ptr(a, dt):
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data
+        d = _lib.ModelDesc()
+        d.n_q, d.n_joints = kin.n_q, kin.n_joints
+        d.joint_parent = ptr(kin.joint_parent, np.int32)
+        d.joint_type = ptr(kin.joint_type, np.int32)
+        d.joint_qidx = ptr(kin.joint_qidx, np.int32)
+        d.joint_rot = ptr(kin.joint_rot, np.float64)
+        d.joint_trans = ptr(kin.joint_trans, np.float64)
+        d.joint_slide = ptr(kin.joint_slide, np.float64)
+        d.joint_axis = ptr(kin.joint_axis, np.float64)
+        d.base_pose = ptr(kin.base_pose, np.float64)
+        if scene is not None:
+            d.n_rshapes, d.n_wshapes, d.n_pairs = scene.n_rshapes, scene.n_wshapes, scene.n_pairs
+            d.rshape_frame = ptr(scene.rshape_frame, np.int32)
+            d.rshape_type = ptr(scene.rshape_type, np.int32)
+            d.rshape_local = ptr(scene.rshape_local, np.float64)
+            d.rshape_param = ptr(scene.rshape_param, np.float64)
+            d.wshape_type = ptr(scene.wshape_type, np.int32)
+            d.wshape_pose = ptr(scene.wshape_pose, np.float64)
+            d.wshape_param = ptr(scene.wshape_param, np.float64)
+            d.pair_a = ptr(scene.pair_a, np.int32)
+            d.pair_b = ptr(scene.pair_b, np.int32)
+        h = C.c_void_p()
+        _lib.check(lib.nbk_model_create(C.byref(d), C.byref(h)), "nbk_model_create")
+        self._h = h
+        self._lib = lib
+        self.n_q = kin.n_q
+        self.n_pairs = scene.n_pairs if scene is not None else 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._lib.nbk_model_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(_torch().cuda.current_stream().cuda_stream)
+
+    # ---- kinematics ----------------------------------------------------------------------------
+    def _frame_args(self, frame, extra_local):
+        fr = self.kin.frames[frame]
+        local = fr.local if extra_local is None else fr.local @ extra_local
+        path = np.ascontiguousarray(fr.path, dtype=np.int32)
+        return path, np.ascontiguousarray(local[:3, :4], dtype=np.float64).reshape(12)
+
+    def fk(self, q, frame, extra_local=None, local_pose=None):
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        path, local = self._frame_args(frame, extra_local)
+        out = torch.empty((qs.B, 4, 4), dtype=torch.float64, device=qs.device)
+        lp = None
+        if local_pose is not None:
+            lp = _Staged(local_pose, 16, "local_pose")
+            if lp.B != qs.B:
+                raise ValueError("local_pose must have one 4x4 per configuration")
+        _lib.check(self._lib.nbk_fk_batch(self._h, qs.t.data_ptr(), qs.B, path.ctypes.data, len(path),
+                                          local.ctypes.data, None if lp is None else lp.t.data_ptr(),
+                                          out.data_ptr(), self._stream()), "nbk_fk_batch")
+        return qs.out(out)
+
+    def jacobian(self, q, frame, extra_local=None, local_pose=None, global_pose=None):
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        path, local = self._frame_args(frame, extra_local)
+        out = torch.empty((qs.B, 6, self.n_q), dtype=torch.float64, device=qs.device)
+        mode, pose = 0, None
+        if local_pose is not None:
+            mode, pose = 1, _Staged(local_pose, 16)
+        elif global_pose is not None:
+            mode, pose = 2, _Staged(global_pose, 16)
+        if pose is not None and pose.B != qs.B:
+            raise ValueError("pose must have one 4x4 per configuration")
+        _lib.check(self._lib.nbk_jacobian_batch(self._h, qs.t.data_ptr(), qs.B, path.ctypes.data, len(path),
+                                                local.ctypes.data, mode, None if pose is None else pose.t.data_ptr(),
+                                                out.data_ptr(), self._stream()), "nbk_jacobian_batch")
+        return qs.out(out)
+
+    # ---- collision -----------------------------------------------------------------------------
+    def validity(self, q, threshold=0.0, packed=False):
+        """In-collision flags.  packed=False: (B,) bool; packed=True: (ceil(B/64),) int64 words
+        (bit b%64 of word b//64), the form the multi-GPU all-gather moves."""
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        if packed:
+            words = torch.zeros(((qs.B + 63) // 64,), dtype=torch.int64, device=qs.device)
+            _lib.check(self._lib.nbk_validity_batch(self._h, qs.t.data_ptr(), qs.B, float(threshold),
+                                                    words.data_ptr(), None, self._stream()), "nbk_validity_batch")
+            return qs.out(words)
+        mask = torch.empty((qs.B,), dtype=torch.uint8, device=qs.device)
+        _lib.check(self._lib.nbk_validity_batch(self._h, qs.t.data_ptr(), qs.B, float(threshold), None,
+                                                mask.data_ptr(), self._stream()), "nbk_validity_batch")
+        return qs.out(mask.bool())
+
+    def closest(self, q):
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        d = torch.empty((qs.B,), dtype=torch.float64, device=qs.device)
+        idx = torch.empty((qs.B,), dtype=torch.int32, device=qs.device)
+        _lib.check(self._lib.nbk_closest_batch(self._h, qs.t.data_ptr(), qs.B, d.data_ptr(), idx.data_ptr(),
+                                               self._stream()), "nbk_closest_batch")
+        return qs.out(d), qs.out(idx)
+
+    def pair_distances(self, q, witness=False):
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        d = torch.empty((qs.B, self.n_pairs), dtype=torch.float64, device=qs.device)
+        w = torch.empty((qs.B, self.n_pairs, 9), dtype=torch.float64, device=qs.device) if witness else None
+        _lib.check(self._lib.nbk_pair_distances_batch(self._h, qs.t.data_ptr(), qs.B, d.data_ptr(),
+                                                      None if w is None else w.data_ptr(), self._stream()),
+                   "nbk_pair_distances_batch")
+        return (qs.out(d), qs.out(w)) if witness else qs.out(d)
+
+    def edge_validity(self, starts, goals, resolution, max_distance, mode="connect", threshold=0.0, dist=None):
+        torch = _require_gpu()
+        s = _Staged(starts, self.n_q)
+        g = _Staged(goals, self.n_q)
+        if s.B != g.B:
+            raise ValueError("starts and goals must have the same number of rows")
+        dd = None
+        if dist is not None:
+            dd = _Staged(dist, 1)
+            if dd.B != s.B:
+                raise ValueError("dist must have one value per edge")
+        valid = torch.empty((s.B,), dtype=torch.uint8, device=s.device)
+        end = torch.empty((s.B, self.n_q), dtype=torch.float64, device=s.device)
+        ns = torch.empty((s.B,), dtype=torch.int32, device=s.device)
+        _lib.check(self._lib.nbk_edge_validity_batch(
+            self._h, s.t.data_ptr(), g.t.data_ptr(), None if dd is None else dd.t.data_ptr(), s.B,
+            float(resolution), float(max_distance), 0 if mode == "connect" else 1, float(threshold),
+            valid.data_ptr(), end.data_ptr(), ns.data_ptr(), self._stream()), "nbk_edge_validity_batch")
+        return s.out(valid.bool()), s.out(end), s.out(ns)
+
+
+def selftest_math(a, b):
+    """sincos(a), sqrt(a), a/b as the kernels compute them (arithmetic-contract check)."""
+    torch = _require_gpu()
+    lib = _lib.load()
+    ta = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    tb = torch.from_numpy(np.ascontiguousarray(b, dtype=np.float64)).cuda()
+    outs = [torch.empty_like(ta) for _ in range(4)]
+    _lib.check(lib.nbk_selftest_math(ta.data_ptr(), tb.data_ptr(), ta.numel(), *[o.data_ptr() for o in outs],
+                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nbk_selftest_math")
+    return [o.cpu().numpy() for o in outs]

@@ -1,0 +1,126 @@
+"""``ConnectorParams`` / ``DiscreteConnector`` (reference: numbotics/planning/sampling_based/connectors.py:12-104).
+
+``connect`` / ``steer`` / ``is_valid`` keep the scalar contract (``copy(goal)`` / ``traj(T_f)`` / ``None``).
+Additive: when the params carry an ``arm`` (instead of, or next to, a Python ``validity_checker``) the
+whole edge -- every sample ``T = arange(0, T_f, res/d) U {T_f}`` -- is checked by ONE device launch,
+and ``connect_batch`` / ``steer_batch`` check E edges per launch (one edge per wavefront).
+``ContinuousConnector`` (connectors.py:108-185, SciPy SLSQP per sub-interval) is out of scope.
+"""
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+
+from numbotics_amd.planning import unit_bspline
+
+_DEFAULT_TRAJ = lambda x, y: unit_bspline(np.array([x, y]))      # noqa: E731
+_DEFAULT_DIST = lambda x, y: np.linalg.norm(x - y)               # noqa: E731
+
+
+@dataclass(frozen=True)
+class ConnectorParams:
+    resolution: float = 5e-2
+    max_distance: float = 1.0
+    trajectory_func: Callable = _DEFAULT_TRAJ
+    validity_checker: Optional[Callable] = None
+    # additive: device-side validity = not arm.in_collision(q, collision_threshold)
+    arm: object = None
+    collision_threshold: float = 0.0
+
+    def __post_init__(self):
+        if self.resolution <= 0:
+            raise ValueError("Resolution must be positive")
+        if self.resolution < 0.0 or self.resolution >= 1.0:
+            raise ValueError("Resolution must be strictly between 0.0 and 1.0")
+        if self.max_distance <= 0:
+            raise ValueError("Max distance must be positive")
+        if self.validity_checker is None and self.arm is None:
+            raise ValueError("Validity checker must be provided")
+        if self.trajectory_func is None:
+            raise ValueError("Trajectory conversion function must be provided")
+
+
+class Connector(ABC):
+    @abstractmethod
+    def connect(self, start, goal):
+        raise NotImplementedError
+
+    @abstractmethod
+    def steer(self, start, goal):
+        raise NotImplementedError
+
+    @abstractmethod
+    def is_valid(self, state):
+        raise NotImplementedError
+
+
+class DiscreteConnector(Connector):
+
+    def __init__(self, params: ConnectorParams):
+        self._params = params
+
+    # ---- scalar contract -----------------------------------------------------------------------------
+    def _device_edge(self):
+        p = self._params
+        return p.arm is not None and p.validity_checker is None and p.trajectory_func is _DEFAULT_TRAJ
+
+    def _walk(self, start, goal, distance, T_f):
+        p = self._params
+        trajectory = p.trajectory_func(start, goal)
+        T = np.append(np.arange(0.0, T_f, p.resolution / distance), T_f)
+        for t in T:
+            if not self.is_valid(trajectory(t)):
+                return None
+        return trajectory
+
+    def connect(self, start, goal, distance_func=_DEFAULT_DIST):
+        distance = distance_func(start, goal)
+        if distance <= np.finfo(np.float32).eps:
+            return None
+        if self._device_edge():
+            ok, _, _ = self._batch(start[None], goal[None], "connect", np.array([distance], dtype=np.float64))
+            return np.copy(goal) if bool(ok[0]) else None
+        if self._walk(start, goal, distance, 1.0) is None:
+            return None
+        return np.copy(goal)
+
+    def steer(self, start, goal, distance_func=_DEFAULT_DIST):
+        distance = distance_func(start, goal)
+        if distance <= np.finfo(np.float32).eps:
+            return None
+        if self._device_edge():
+            ok, end, _ = self._batch(start[None], goal[None], "steer", np.array([distance], dtype=np.float64))
+            return np.copy(end[0]) if bool(ok[0]) else None
+        T_f = 1.0 if distance <= self._params.max_distance else self._params.max_distance / distance
+        trajectory = self._walk(start, goal, distance, T_f)
+        if trajectory is None:
+            return None
+        return np.copy(trajectory(T_f))
+
+    def is_valid(self, state):
+        p = self._params
+        if p.validity_checker is not None:
+            return p.validity_checker(state)
+        return not p.arm.in_collision(state, p.collision_threshold)
+
+    # ---- batched (additive) ------------------------------------------------------------------------------
+    def _batch(self, starts, goals, mode, dist=None):
+        p = self._params
+        if p.arm is None:
+            raise ValueError("batched edge checks need ConnectorParams(arm=...)")
+        if p.trajectory_func is not _DEFAULT_TRAJ:
+            raise ValueError("batched edge checks support the default linear trajectory only")
+        _, dev = p.arm._scene_device()
+        return dev.edge_validity(starts, goals, p.resolution, p.max_distance, mode=mode,
+                                 threshold=p.collision_threshold, dist=dist)
+
+    def connect_batch(self, starts, goals, dist=None):
+        """(E, dof) x (E, dof) -> (E,) bool: True where ``connect`` would return the goal."""
+        return self._batch(starts, goals, "connect", dist)[0]
+
+    def steer_batch(self, starts, goals, dist=None):
+        """-> ((E,) bool, (E, dof) end states ``traj(T_f)``); rows of invalid edges are what they would
+        have been returned had the edge been free."""
+        ok, end, _ = self._batch(starts, goals, "steer", dist)
+        return ok, end

@@ -1,0 +1,64 @@
+"""The benchmark / test scenes of BASELINE.json's configs, built through the public API.
+
+c1 : Kinova-like arm alone (FK plumbing config).
+c2 : arm + one Cube(half_extent=0.4) at [1.0, 0.0, 0.2] (reference README.md:96); self pairs = default
+     rule minus the hand removals of numbotics/tests/_test_rrt.py:38-61.
+c3 : arm + 8 Cube(half_extent=0.25) on a ring of radius 0.9 m, heights alternating 0.25 / 0.75 m, angles
+     k*45 deg (build-defined: the reference has no 8-cube scene).
+The Kinova URDF is this build's own asset (numbotics_amd/models/kinova_cyl.urdf).
+"""
+import os
+from itertools import combinations
+
+import numpy as np
+
+KINOVA_URDF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "kinova_cyl.urdf")
+
+_WRIST_GROUP = [
+    'spherical_wrist_1_link', 'spherical_wrist_2_link', 'bracelet_link', 'end_effector_link', 'camera_link',
+    'camera_depth_frame', 'camera_color_frame', 'tool_frame', 'robotiq_arg2f_base_link', 'gripper', 'camera',
+]
+
+
+def apply_rrt_script_removals(arm):
+    """The self-pair removals the reference's PRM demo performs by hand (_test_rrt.py:38-61)."""
+    from numbotics_amd.utils import logger
+    verbose, logger.VERBOSE = logger.VERBOSE, False
+    try:
+        arm.remove_collision_pair('base_link', 'half_arm_1_link')
+        arm.remove_collision_pair('half_arm_2_link', 'spherical_wrist_1_link')
+        for a, b in combinations(_WRIST_GROUP, 2):
+            arm.remove_collision_pair(a, b)
+    finally:
+        logger.VERBOSE = verbose
+
+
+def build_scene(name: str = "c2", urdf: str = KINOVA_URDF):
+    """-> (arm, chain, obstacles).  Keep the returned obstacles alive: the world holds weak references."""
+    from numbotics_amd.physics import GraphChain, Cube
+    from numbotics_amd.robots import Arm
+    chain = GraphChain.from_urdf(urdf)
+    arm = Arm(chain)
+    obstacles = []
+    if name == "c1":
+        pass
+    elif name == "c2":
+        obstacles.append(Cube(half_extent=0.4, mass=0.0, position=np.array([1.0, 0.0, 0.2])))
+        apply_rrt_script_removals(arm)
+    elif name == "c3":
+        for k in range(8):
+            ang = np.deg2rad(45.0 * k)
+            z = 0.25 if k % 2 == 0 else 0.75
+            obstacles.append(Cube(half_extent=0.25, mass=0.0,
+                                  position=np.array([0.9 * np.cos(ang), 0.9 * np.sin(ang), z])))
+        apply_rrt_script_removals(arm)
+    else:
+        raise ValueError(f"unknown scene '{name}'")
+    return arm, chain, obstacles
+
+
+def sample_q(chain, B: int, seed: int = 1, margin: float = 0.0):
+    """q ~ U(lower + margin, upper - margin), float64 (B, dof), numpy default_rng(seed)."""
+    rng = np.random.default_rng(seed)
+    lim = chain.joint_limits
+    return rng.uniform(lim[:, 0] + margin, lim[:, 1] - margin, (B, chain.dof))

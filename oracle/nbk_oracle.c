@@ -1,0 +1,1009 @@
+/*
+ * oracle/nbk_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See nbk_oracle.h.
+ *
+ * Build: gcc -O2 -ffp-contract=off -mfma -fPIC -shared -pthread nbk_oracle.c -lm   (oracle/Makefile)
+ * -ffp-contract=off + explicit fma() = the arithmetic contract of DESIGN.md: every rounding below is
+ * written out, so an independent implementation that follows the same order is bit-identical.
+ */
+#include "nbk_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FMA(a, b, c) fma((a), (b), (c))
+
+/* ------------------------------------------------------------------------------------------------
+ * small vector helpers (operation order is part of the contract)
+ * ---------------------------------------------------------------------------------------------- */
+static inline double dot3(const double *a, const double *b) {
+    return FMA(a[2], b[2], FMA(a[1], b[1], a[0] * b[0]));
+}
+static inline void sub3(const double *a, const double *b, double *o) {
+    o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2];
+}
+static inline void cross3(const double *a, const double *b, double *o) {
+    o[0] = FMA(a[1], b[2], -(a[2] * b[1]));
+    o[1] = FMA(a[2], b[0], -(a[0] * b[2]));
+    o[2] = FMA(a[0], b[1], -(a[1] * b[0]));
+}
+/* o = a + s*b */
+static inline void axpy3(double s, const double *b, const double *a, double *o) {
+    o[0] = FMA(s, b[0], a[0]); o[1] = FMA(s, b[1], a[1]); o[2] = FMA(s, b[2], a[2]);
+}
+static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* 3x4 transforms: R row-major [9], t [3] */
+typedef struct { double R[9]; double t[3]; } xf_t;
+
+static inline void xf_from12(const double *p, xf_t *x) {
+    for (int i = 0; i < 3; ++i) {
+        x->R[3 * i + 0] = p[4 * i + 0]; x->R[3 * i + 1] = p[4 * i + 1]; x->R[3 * i + 2] = p[4 * i + 2];
+        x->t[i] = p[4 * i + 3];
+    }
+}
+/* o = a * b  (b: rotation Rb, translation tb) */
+static inline void xf_mul(const xf_t *a, const double *Rb, const double *tb, xf_t *o) {
+    for (int i = 0; i < 3; ++i) {
+        const double a0 = a->R[3 * i], a1 = a->R[3 * i + 1], a2 = a->R[3 * i + 2];
+        for (int j = 0; j < 3; ++j)
+            o->R[3 * i + j] = FMA(a2, Rb[6 + j], FMA(a1, Rb[3 + j], a0 * Rb[j]));
+        o->t[i] = FMA(a2, tb[2], FMA(a1, tb[1], FMA(a0, tb[0], a->t[i])));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * sincos: Cody-Waite reduction by pi/2 (three 33-bit pieces, fused) + fdlibm minimax kernels.
+ * Defined for |x| < 2^31; otherwise (and for NaN) both results are NaN.
+ * ---------------------------------------------------------------------------------------------- */
+static const double TWO_OVER_PI = 6.36619772367581382433e-01;
+static const double PIO2_1 = 1.57079632673412561417e+00;
+static const double PIO2_2 = 6.07710050630396597660e-11;
+static const double PIO2_3 = 2.02226624871116645580e-21;
+static const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                    S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                    S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+static const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                    C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                    C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+
+void orc_sincos(double x, double *s, double *c) {
+    if (!(fabs(x) < 2147483648.0)) { *s = NAN; *c = NAN; return; }
+    const double k = rint(x * TWO_OVER_PI);
+    double r = FMA(-k, PIO2_1, x);
+    r = FMA(-k, PIO2_2, r);
+    r = FMA(-k, PIO2_3, r);
+    const double z = r * r;
+    double ps = FMA(z, S6, S5);
+    ps = FMA(z, ps, S4); ps = FMA(z, ps, S3); ps = FMA(z, ps, S2); ps = FMA(z, ps, S1);
+    const double sr = FMA(r * z, ps, r);
+    double pc = FMA(z, C6, C5);
+    pc = FMA(z, pc, C4); pc = FMA(z, pc, C3); pc = FMA(z, pc, C2); pc = FMA(z, pc, C1);
+    const double cr = FMA(z * z, pc, FMA(-0.5, z, 1.0));
+    const int n = (int)((long long)k & 3LL);
+    switch (n) {
+        case 0: *s = sr; *c = cr; break;
+        case 1: *s = cr; *c = -sr; break;
+        case 2: *s = -sr; *c = -cr; break;
+        default: *s = -cr; *c = sr; break;
+    }
+}
+void orc_sincos_array(const double *x, int64_t n, double *s, double *c) {
+    for (int64_t i = 0; i < n; ++i) orc_sincos(x[i], &s[i], &c[i]);
+}
+void orc_sqrt_div_array(const double *a, const double *b, int64_t n, double *sq, double *dv) {
+    for (int64_t i = 0; i < n; ++i) { sq[i] = sqrt(a[i]); dv[i] = a[i] / b[i]; }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * kinematics
+ * ---------------------------------------------------------------------------------------------- */
+/* child frame of joint k given the parent frame and q (helpers.py:43-55 restated with M0/M1/M2) */
+static void joint_apply(const orc_model *m, int k, const xf_t *parent, const double *q, xf_t *out) {
+    const double *M = m->joint_rot + 27 * k;
+    const double *toff = m->joint_trans + 3 * k;
+    const double *sl = m->joint_slide + 3 * k;
+    const double qk = q[m->joint_qidx[k]];
+    double s = 0.0, c = 0.0;
+    if (m->joint_type[k] == ORC_REVOLUTE) orc_sincos(qk, &s, &c);
+    double L[9], tl[3];
+    for (int e = 0; e < 9; ++e) L[e] = FMA(s, M[18 + e], FMA(-c, M[9 + e], M[e]));
+    for (int i = 0; i < 3; ++i) tl[i] = FMA(qk, sl[i], toff[i]);
+    xf_mul(parent, L, tl, out);
+}
+
+static void sweep_path(const orc_model *m, const double *q, const int32_t *path, int32_t path_len, xf_t *T,
+                       xf_t *frames /* optional [path_len] */) {
+    xf_from12(m->base_pose, T);
+    for (int i = 0; i < path_len; ++i) {
+        xf_t nxt;
+        joint_apply(m, path[i], T, q, &nxt);
+        *T = nxt;
+        if (frames) frames[i] = nxt;
+    }
+}
+
+static void xf_to16(const xf_t *x, double *o) {
+    for (int i = 0; i < 3; ++i) {
+        o[4 * i + 0] = x->R[3 * i]; o[4 * i + 1] = x->R[3 * i + 1]; o[4 * i + 2] = x->R[3 * i + 2];
+        o[4 * i + 3] = x->t[i];
+    }
+    o[12] = 0.0; o[13] = 0.0; o[14] = 0.0; o[15] = 1.0;
+}
+static void xf_from16(const double *p, xf_t *x) {
+    for (int i = 0; i < 3; ++i) {
+        x->R[3 * i + 0] = p[4 * i + 0]; x->R[3 * i + 1] = p[4 * i + 1]; x->R[3 * i + 2] = p[4 * i + 2];
+        x->t[i] = p[4 * i + 3];
+    }
+}
+
+int orc_fk(const orc_model *m, const double *q, int64_t B, const int32_t *path, int32_t path_len,
+           const double *local, const double *local_pose, double *out) {
+    xf_t loc;
+    xf_from12(local, &loc);
+    for (int64_t b = 0; b < B; ++b) {
+        xf_t T, E;
+        sweep_path(m, q + b * m->n_q, path, path_len, &T, NULL);
+        xf_mul(&T, loc.R, loc.t, &E);
+        if (local_pose) {
+            xf_t lp, E2;
+            xf_from16(local_pose + 16 * b, &lp);
+            xf_mul(&E, lp.R, lp.t, &E2);
+            E = E2;
+        }
+        xf_to16(&E, out + 16 * b);
+    }
+    return 0;
+}
+
+int orc_jacobian(const orc_model *m, const double *q, int64_t B, const int32_t *path, int32_t path_len,
+                 const double *local, int32_t mode, const double *pose, double *out) {
+    xf_t loc;
+    xf_from12(local, &loc);
+    const int nq = m->n_q;
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(path_len > 0 ? path_len : 1));
+    if (!frames) return -1;
+    for (int64_t b = 0; b < B; ++b) {
+        double *J = out + (size_t)b * 6 * nq;
+        memset(J, 0, sizeof(double) * 6 * (size_t)nq);
+        xf_t T, E;
+        sweep_path(m, q + b * nq, path, path_len, &T, frames);
+        xf_mul(&T, loc.R, loc.t, &E);
+        double pend[3];
+        if (mode == 1) {
+            xf_t lp, E2;
+            xf_from16(pose + 16 * b, &lp);
+            xf_mul(&E, lp.R, lp.t, &E2);
+            pend[0] = E2.t[0]; pend[1] = E2.t[1]; pend[2] = E2.t[2];
+        } else if (mode == 2) {
+            pend[0] = pose[16 * b + 3]; pend[1] = pose[16 * b + 7]; pend[2] = pose[16 * b + 11];
+        } else {
+            pend[0] = E.t[0]; pend[1] = E.t[1]; pend[2] = E.t[2];
+        }
+        for (int i = 0; i < path_len; ++i) {
+            const int k = path[i];
+            const double *a = m->joint_axis + 3 * k;
+            const xf_t *F = &frames[i];
+            double w[3];
+            for (int r = 0; r < 3; ++r) w[r] = FMA(F->R[3 * r + 2], a[2], FMA(F->R[3 * r + 1], a[1], F->R[3 * r] * a[0]));
+            const int col = m->joint_qidx[k];
+            if (m->joint_type[k] == ORC_REVOLUTE) {
+                double d[3], v[3];
+                sub3(pend, F->t, d);
+                cross3(w, d, v);
+                J[0 * nq + col] = v[0]; J[1 * nq + col] = v[1]; J[2 * nq + col] = v[2];
+                J[3 * nq + col] = w[0]; J[4 * nq + col] = w[1]; J[5 * nq + col] = w[2];
+            } else {
+                J[0 * nq + col] = w[0]; J[1 * nq + col] = w[1]; J[2 * nq + col] = w[2];
+            }
+        }
+    }
+    free(frames);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * narrowphase.  Every shape = convex core (+) ball(margin):
+ *   sphere   : point,            margin r
+ *   capsule  : segment c +- hl u, margin r            (u = local z)
+ *   box      : box he - m,       margin m (default 0)
+ *   cylinder : cylinder (R - m, hl - m), margin m (default 0)   (axis = local z)
+ * signed distance d = dist(coreA, coreB) - mA - mB when the cores are disjoint (exact), and
+ * d = -depth(coreA, coreB) - mA - mB when they overlap, depth = minimum overlap over the candidate
+ * axis family below (exact MTD for point/segment/box cores, an upper bound when a cylinder core is
+ * involved).
+ * ---------------------------------------------------------------------------------------------- */
+enum { K_POINT = 0, K_SEG = 1, K_BOX = 2, K_CYL = 3, K_PLANE = 4 };
+
+typedef struct {
+    int kind;
+    double c[3];
+    double ax[3][3]; /* ax[j] = world direction of local axis j (column j of R) */
+    double h[3];     /* seg: h[0] = half length; cyl: h[0] = half height; box: half extents (core) */
+    double rad;      /* cyl core radius */
+    double margin;
+} core_t;
+
+static void core_from_shape(int type, const xf_t *pose, const double *param, core_t *o) {
+    o->c[0] = pose->t[0]; o->c[1] = pose->t[1]; o->c[2] = pose->t[2];
+    for (int j = 0; j < 3; ++j) { o->ax[j][0] = pose->R[j]; o->ax[j][1] = pose->R[3 + j]; o->ax[j][2] = pose->R[6 + j]; }
+    o->h[0] = o->h[1] = o->h[2] = 0.0; o->rad = 0.0; o->margin = 0.0;
+    switch (type) {
+        case ORC_SPHERE: o->kind = K_POINT; o->margin = param[0]; break;
+        case ORC_CAPSULE: o->kind = K_SEG; o->margin = param[0]; o->h[0] = param[1]; break;
+        case ORC_BOX:
+            o->kind = K_BOX; o->margin = param[3];
+            o->h[0] = param[0] - param[3]; o->h[1] = param[1] - param[3]; o->h[2] = param[2] - param[3];
+            break;
+        case ORC_CYLINDER:
+            o->kind = K_CYL; o->margin = param[3];
+            o->rad = param[0] - param[3]; o->h[0] = param[1] - param[3];
+            break;
+        default: /* plane: normal in param[0..2], point = pose translation */
+            o->kind = K_PLANE; o->ax[2][0] = param[0]; o->ax[2][1] = param[1]; o->ax[2][2] = param[2];
+            break;
+    }
+}
+
+/* support point of a core in direction d */
+static void core_support(const core_t *s, const double *d, double *o) {
+    switch (s->kind) {
+        case K_POINT: o[0] = s->c[0]; o[1] = s->c[1]; o[2] = s->c[2]; break;
+        case K_SEG: {
+            const double du = dot3(d, s->ax[2]);
+            const double sg = du >= 0.0 ? s->h[0] : -s->h[0];
+            axpy3(sg, s->ax[2], s->c, o);
+        } break;
+        case K_CYL: {
+            const double *u = s->ax[2];
+            const double du = dot3(d, u);
+            const double sg = du >= 0.0 ? s->h[0] : -s->h[0];
+            double w[3];
+            axpy3(-du, u, d, w);
+            axpy3(-dot3(w, u), u, w, w);   /* second Gram-Schmidt pass: when d is almost axial the first
+                                              difference cancels and w would keep an axial component that
+                                              the normalisation below blows up to O(rad) */
+            const double ww = dot3(w, w);
+            axpy3(sg, u, s->c, o);
+            if (ww > 0.0) {
+                const double k = s->rad / sqrt(ww);
+                axpy3(k, w, o, o);
+            }
+        } break;
+        default: { /* box */
+            o[0] = s->c[0]; o[1] = s->c[1]; o[2] = s->c[2];
+            for (int j = 0; j < 3; ++j) {
+                const double dj = dot3(d, s->ax[j]);
+                const double sj = dj >= 0.0 ? s->h[j] : -s->h[j];
+                axpy3(sj, s->ax[j], o, o);
+            }
+        } break;
+    }
+}
+
+/* half-width of a (centrally symmetric) core along unit direction n */
+static double core_halfwidth(const core_t *s, const double *n) {
+    switch (s->kind) {
+        case K_POINT: return 0.0;
+        case K_SEG: return s->h[0] * fabs(dot3(n, s->ax[2]));
+        case K_CYL: {
+            const double nu = dot3(n, s->ax[2]);
+            const double r2 = FMA(-nu, nu, 1.0);
+            return FMA(s->rad, sqrt(r2 > 0.0 ? r2 : 0.0), s->h[0] * fabs(nu));
+        }
+        default:
+            return FMA(s->h[2], fabs(dot3(n, s->ax[2])), FMA(s->h[1], fabs(dot3(n, s->ax[1])), s->h[0] * fabs(dot3(n, s->ax[0]))));
+    }
+}
+
+/* ---- GJK on cores -------------------------------------------------------------------------- */
+#define GJK_MAXIT 64
+static const double GJK_EPS_REL = 1e-10;
+static const double GJK_TINY2 = 1e-30;
+
+typedef struct { double y[4][3], a[4][3], b[4][3]; double lam[4]; int n; } simplex_t;
+
+static void sx_keep(simplex_t *s, const int *idx, const double *lam, int n) {
+    simplex_t t = *s;
+    for (int i = 0; i < n; ++i) {
+        memcpy(s->y[i], t.y[idx[i]], sizeof(double) * 3);
+        memcpy(s->a[i], t.a[idx[i]], sizeof(double) * 3);
+        memcpy(s->b[i], t.b[idx[i]], sizeof(double) * 3);
+        s->lam[i] = lam[i];
+    }
+    s->n = n;
+}
+
+/* closest point to the origin on segment (i0,i1); writes v, returns kept count/idx/lam */
+static int closest_seg(const simplex_t *s, int i0, int i1, double *v, int *idx, double *lam) {
+    const double *A = s->y[i0], *Bp = s->y[i1];
+    double ab[3];
+    sub3(Bp, A, ab);
+    const double t = -dot3(A, ab);
+    if (t <= 0.0) { v[0] = A[0]; v[1] = A[1]; v[2] = A[2]; idx[0] = i0; lam[0] = 1.0; return 1; }
+    const double den = dot3(ab, ab);
+    if (t >= den) { v[0] = Bp[0]; v[1] = Bp[1]; v[2] = Bp[2]; idx[0] = i1; lam[0] = 1.0; return 1; }
+    const double tt = t / den;
+    axpy3(tt, ab, A, v);
+    idx[0] = i0; idx[1] = i1; lam[0] = 1.0 - tt; lam[1] = tt;
+    return 2;
+}
+
+/* closest point to the origin on triangle (i0,i1,i2) -- Voronoi-region walk */
+static int closest_tri(const simplex_t *s, int i0, int i1, int i2, double *v, int *idx, double *lam) {
+    const double *A = s->y[i0], *Bp = s->y[i1], *Cp = s->y[i2];
+    double ab[3], ac[3];
+    sub3(Bp, A, ab); sub3(Cp, A, ac);
+    const double d1 = -dot3(ab, A), d2 = -dot3(ac, A);
+    if (d1 <= 0.0 && d2 <= 0.0) { memcpy(v, A, 24); idx[0] = i0; lam[0] = 1.0; return 1; }
+    const double d3 = -dot3(ab, Bp), d4 = -dot3(ac, Bp);
+    if (d3 >= 0.0 && d4 <= d3) { memcpy(v, Bp, 24); idx[0] = i1; lam[0] = 1.0; return 1; }
+    const double vc = FMA(d1, d4, -(d3 * d2));
+    if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
+        const double t = d1 / (d1 - d3);
+        axpy3(t, ab, A, v);
+        idx[0] = i0; idx[1] = i1; lam[0] = 1.0 - t; lam[1] = t;
+        return 2;
+    }
+    const double d5 = -dot3(ab, Cp), d6 = -dot3(ac, Cp);
+    if (d6 >= 0.0 && d5 <= d6) { memcpy(v, Cp, 24); idx[0] = i2; lam[0] = 1.0; return 1; }
+    const double vb = FMA(d5, d2, -(d1 * d6));
+    if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
+        const double t = d2 / (d2 - d6);
+        axpy3(t, ac, A, v);
+        idx[0] = i0; idx[1] = i2; lam[0] = 1.0 - t; lam[1] = t;
+        return 2;
+    }
+    const double va = FMA(d3, d6, -(d5 * d4));
+    if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+        const double t = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        double bc[3];
+        sub3(Cp, Bp, bc);
+        axpy3(t, bc, Bp, v);
+        idx[0] = i1; idx[1] = i2; lam[0] = 1.0 - t; lam[1] = t;
+        return 2;
+    }
+    const double den = 1.0 / (va + vb + vc);
+    const double tv = vb * den, tw = vc * den;
+    double tmp[3];
+    axpy3(tv, ab, A, tmp);
+    axpy3(tw, ac, tmp, v);
+    idx[0] = i0; idx[1] = i1; idx[2] = i2; lam[0] = (1.0 - tv) - tw; lam[1] = tv; lam[2] = tw;
+    return 3;
+}
+
+/* origin outside the plane of (a,b,c) on the side away from d?  flat tetrahedra count as outside */
+static int outside_face(const double *a, const double *b, const double *c, const double *d) {
+    double ab[3], ac[3], ad[3], n[3];
+    sub3(b, a, ab); sub3(c, a, ac); sub3(d, a, ad);
+    cross3(ab, ac, n);
+    const double sp = -dot3(a, n);
+    const double sd = dot3(ad, n);
+    return (sp * sd < 0.0) || (sd == 0.0);
+}
+
+/* returns 1 if the origin is inside the tetrahedron (overlap), else reduces the simplex */
+static int closest_tet(simplex_t *s, double *v) {
+    static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};
+    double best = INFINITY;
+    int bidx[3] = {0, 0, 0}, bn = 0;
+    double blam[3] = {0, 0, 0}, bv[3] = {0, 0, 0};
+    int any = 0;
+    for (int f = 0; f < 4; ++f) {
+        if (!outside_face(s->y[F[f][0]], s->y[F[f][1]], s->y[F[f][2]], s->y[F[f][3]])) continue;
+        any = 1;
+        double cv[3], clam[3];
+        int cidx[3];
+        const int cn = closest_tri(s, F[f][0], F[f][1], F[f][2], cv, cidx, clam);
+        const double dd = dot3(cv, cv);
+        if (dd < best) {
+            best = dd; bn = cn;
+            for (int i = 0; i < cn; ++i) { bidx[i] = cidx[i]; blam[i] = clam[i]; }
+            bv[0] = cv[0]; bv[1] = cv[1]; bv[2] = cv[2];
+        }
+    }
+    if (!any) return 1;
+    v[0] = bv[0]; v[1] = bv[1]; v[2] = bv[2];
+    sx_keep(s, bidx, blam, bn);
+    return 0;
+}
+
+/* one simplex update shared by the distance and the predicate loops.
+ * returns 0 = advanced (v, vv_prev updated), 1 = origin enclosed / touching, 2 = no progress (simplex restored) */
+static int gjk_advance(simplex_t *sx, const double *w, const double *sa, const double *sb, double *v, double *vv_prev) {
+    const int k = sx->n;
+    memcpy(sx->y[k], w, 24); memcpy(sx->a[k], sa, 24); memcpy(sx->b[k], sb, 24);
+    sx->lam[k] = 0.0;
+    sx->n = k + 1;
+    simplex_t saved = *sx;
+    double nvv[3];
+    int idx[3];
+    double lam[3];
+    int enclosed = 0;
+    if (sx->n == 1) {
+        memcpy(nvv, sx->y[0], 24); sx->lam[0] = 1.0;
+    } else if (sx->n == 2) {
+        const int n = closest_seg(sx, 0, 1, nvv, idx, lam);
+        sx_keep(sx, idx, lam, n);
+    } else if (sx->n == 3) {
+        const int n = closest_tri(sx, 0, 1, 2, nvv, idx, lam);
+        sx_keep(sx, idx, lam, n);
+    } else {
+        enclosed = closest_tet(sx, nvv);
+    }
+    if (enclosed) { *sx = saved; sx->n = k; return 1; }
+    const double nn = dot3(nvv, nvv);
+    if (nn <= GJK_TINY2) { *sx = saved; sx->n = k; return 1; }
+    if (nn >= *vv_prev) { *sx = saved; sx->n = k; return 2; }
+    *vv_prev = nn;
+    v[0] = nvv[0]; v[1] = nvv[1]; v[2] = nvv[2];
+    return 0;
+}
+
+/* GJK distance: returns 1 if the cores overlap (or touch), 0 if separated with v the closest vector
+ * (from B to A) and pa/pb witness points.  `sep` records a proven separating plane (v.w > 0): once set,
+ * a later "enclosed" verdict is numerical breakdown of a degenerate simplex and ends the iteration
+ * instead.  Convergence uses the best lower bound seen so far: |v|^2 - max_k (v_k.w_k)^2/|v_k|^2 <= eps |v|^2. */
+static int gjk_cores(const core_t *A, const core_t *Bc, double *pa, double *pb, double *vout, int *iters_out) {
+    simplex_t sx;
+    sx.n = 0;
+    double v[3];
+    sub3(A->c, Bc->c, v);
+    if (dot3(v, v) == 0.0) { v[0] = 1.0; v[1] = 0.0; v[2] = 0.0; }
+    double vv_prev = INFINITY, lb2 = 0.0;
+    int overlap = 0, sep = 0, it = 0;
+    for (it = 0; it < GJK_MAXIT; ++it) {
+        double nv[3] = {-v[0], -v[1], -v[2]};
+        double sa[3], sb[3], w[3];
+        core_support(A, nv, sa);
+        core_support(Bc, v, sb);
+        sub3(sa, sb, w);
+        const double vv = dot3(v, v);
+        const double vw = dot3(v, w);
+        if (vw > 0.0) {
+            sep = 1;
+            const double l2 = (vw * vw) / vv;
+            if (l2 > lb2) lb2 = l2;
+        }
+        if (sx.n > 0 && (vv - lb2) <= GJK_EPS_REL * vv) break;
+        int dup = 0;
+        for (int i = 0; i < sx.n; ++i)
+            if (sx.y[i][0] == w[0] && sx.y[i][1] == w[1] && sx.y[i][2] == w[2]) dup = 1;
+        if (dup) break;
+        const int st = gjk_advance(&sx, w, sa, sb, v, &vv_prev);
+        if (st == 1) { if (!sep) overlap = 1; ++it; break; }
+        if (st == 2) { ++it; break; }
+    }
+    if (iters_out) *iters_out = it;
+    if (overlap) return 1;
+    vout[0] = v[0]; vout[1] = v[1]; vout[2] = v[2];
+    pa[0] = pa[1] = pa[2] = 0.0; pb[0] = pb[1] = pb[2] = 0.0;
+    for (int i = 0; i < sx.n; ++i) {
+        axpy3(sx.lam[i], sx.a[i], pa, pa);
+        axpy3(sx.lam[i], sx.b[i], pb, pb);
+    }
+    return 0;
+}
+
+static double overlap_depth(const core_t *A, const core_t *Bc, double *normal);
+
+/* GJK predicate: is dist(coreA, coreB) < tc ?  Same iteration as gjk_cores, but it stops as soon as the
+ * support-plane lower bound reaches tc (free) or the simplex point drops below tc (colliding). */
+static int gjk_collides(const core_t *A, const core_t *Bc, double tc) {
+    simplex_t sx;
+    sx.n = 0;
+    double v[3];
+    sub3(A->c, Bc->c, v);
+    if (dot3(v, v) == 0.0) { v[0] = 1.0; v[1] = 0.0; v[2] = 0.0; }
+    double vv_prev = INFINITY, lb2 = 0.0;
+    const double tc2 = tc * tc;
+    int sep = 0;
+    for (int it = 0; it < GJK_MAXIT; ++it) {
+        double nv[3] = {-v[0], -v[1], -v[2]};
+        double sa[3], sb[3], w[3];
+        core_support(A, nv, sa);
+        core_support(Bc, v, sb);
+        sub3(sa, sb, w);
+        const double vv = dot3(v, v);
+        const double vw = dot3(v, w);
+        if (vw > 0.0) {
+            sep = 1;
+            if (tc <= 0.0) return 0;
+            if (vw * vw >= tc2 * vv) return 0;
+            const double l2 = (vw * vw) / vv;
+            if (l2 > lb2) lb2 = l2;
+        }
+        if (sx.n > 0 && (vv - lb2) <= GJK_EPS_REL * vv) break;
+        int dup = 0;
+        for (int i = 0; i < sx.n; ++i)
+            if (sx.y[i][0] == w[0] && sx.y[i][1] == w[1] && sx.y[i][2] == w[2]) dup = 1;
+        if (dup) break;
+        const int st = gjk_advance(&sx, w, sa, sb, v, &vv_prev);
+        if (st == 1) {
+            if (sep) break;
+            if (tc >= 0.0) return 1;
+            double nrm[3];
+            return -overlap_depth(A, Bc, nrm) < tc;
+        }
+        if (st == 2) break;
+        if (tc > 0.0 && vv_prev < tc2) return 1;
+    }
+    return sqrt(dot3(v, v)) < tc;
+}
+
+/* ---- overlap depth over a candidate axis family --------------------------------------------- */
+static void try_axis(const core_t *A, const core_t *Bc, const double *delta, const double *n_in, double *best,
+                     double *bn) {
+    const double nn = dot3(n_in, n_in);
+    if (!(nn > 1e-24)) return;
+    const double inv = 1.0 / sqrt(nn);
+    double n[3] = {n_in[0] * inv, n_in[1] * inv, n_in[2] * inv};
+    const double proj = dot3(n, delta); /* delta = cA - cB */
+    const double ov = (core_halfwidth(A, n) + core_halfwidth(Bc, n)) - fabs(proj);
+    if (ov < *best) {
+        *best = ov;
+        const double sg = proj >= 0.0 ? 1.0 : -1.0; /* normal from B to A */
+        bn[0] = sg * n[0]; bn[1] = sg * n[1]; bn[2] = sg * n[2];
+    }
+}
+
+static int core_axes(const core_t *s, const double **ax) {
+    if (s->kind == K_BOX) { ax[0] = s->ax[0]; ax[1] = s->ax[1]; ax[2] = s->ax[2]; return 3; }
+    if (s->kind == K_SEG || s->kind == K_CYL) { ax[0] = s->ax[2]; return 1; }
+    return 0;
+}
+
+static double overlap_depth(const core_t *A, const core_t *Bc, double *normal) {
+    double delta[3];
+    sub3(A->c, Bc->c, delta);
+    double best = INFINITY;
+    normal[0] = 1.0; normal[1] = 0.0; normal[2] = 0.0;
+    const double *aa[3], *ba[3];
+    const int na = core_axes(A, aa), nb = core_axes(Bc, ba);
+    for (int i = 0; i < na; ++i) try_axis(A, Bc, delta, aa[i], &best, normal);
+    for (int j = 0; j < nb; ++j) try_axis(A, Bc, delta, ba[j], &best, normal);
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) {
+            double cr[3];
+            cross3(aa[i], ba[j], cr);
+            try_axis(A, Bc, delta, cr, &best, normal);
+        }
+    /* radial directions of cylinder cores, and the centre line */
+    if (A->kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A->ax[2]), A->ax[2], delta, r); try_axis(A, Bc, delta, r, &best, normal); }
+    if (Bc->kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc->ax[2]), Bc->ax[2], delta, r); try_axis(A, Bc, delta, r, &best, normal); }
+    try_axis(A, Bc, delta, delta, &best, normal);
+    if (best == INFINITY) best = 0.0; /* two coincident points */
+    return best;
+}
+
+/* ---- closed forms for point / segment cores -------------------------------------------------- */
+static void seg_seg_closest(const core_t *A, const core_t *Bc, double *pa, double *pb) {
+    const double *ua = A->ax[2], *ub = Bc->ax[2];
+    const double ha = A->h[0], hb = Bc->h[0];
+    double r[3];
+    sub3(A->c, Bc->c, r);
+    const double b = dot3(ua, ub), c = dot3(ua, r), f = dot3(ub, r);
+    const double den = FMA(-b, b, 1.0);
+    double s = 0.0;
+    if (den > 1e-14) s = clampd(FMA(b, f, -c) / den, -ha, ha);
+    double t = FMA(b, s, f);
+    if (t < -hb) { t = -hb; s = clampd(FMA(b, t, -c), -ha, ha); }
+    else if (t > hb) { t = hb; s = clampd(FMA(b, t, -c), -ha, ha); }
+    axpy3(s, ua, A->c, pa);
+    axpy3(t, ub, Bc->c, pb);
+}
+
+/* closest points between two cores of kind point/segment */
+static void ps_closest(const core_t *A, const core_t *Bc, double *pa, double *pb) {
+    if (A->kind == K_POINT && Bc->kind == K_POINT) {
+        memcpy(pa, A->c, 24); memcpy(pb, Bc->c, 24);
+    } else if (A->kind == K_POINT) {
+        double d[3];
+        sub3(A->c, Bc->c, d);
+        const double t = clampd(dot3(d, Bc->ax[2]), -Bc->h[0], Bc->h[0]);
+        memcpy(pa, A->c, 24);
+        axpy3(t, Bc->ax[2], Bc->c, pb);
+    } else if (Bc->kind == K_POINT) {
+        double d[3];
+        sub3(Bc->c, A->c, d);
+        const double t = clampd(dot3(d, A->ax[2]), -A->h[0], A->h[0]);
+        axpy3(t, A->ax[2], A->c, pa);
+        memcpy(pb, Bc->c, 24);
+    } else {
+        seg_seg_closest(A, Bc, pa, pb);
+    }
+}
+
+/* point core P against box / cylinder core S: signed core distance, closest surface point, outward normal */
+static double point_solid(const double *p, const core_t *S, double *cp, double *nrm) {
+    double d[3];
+    sub3(p, S->c, d);
+    if (S->kind == K_BOX) {
+        double x[3], qx[3];
+        int outside = 0;
+        for (int j = 0; j < 3; ++j) {
+            x[j] = dot3(d, S->ax[j]);
+            qx[j] = clampd(x[j], -S->h[j], S->h[j]);
+            if (fabs(x[j]) > S->h[j]) outside = 1;
+        }
+        if (outside) {
+            memcpy(cp, S->c, 24);
+            for (int j = 0; j < 3; ++j) axpy3(qx[j], S->ax[j], cp, cp);
+            double e[3];
+            sub3(p, cp, e);
+            const double dist = sqrt(dot3(e, e));
+            const double inv = 1.0 / dist;
+            nrm[0] = e[0] * inv; nrm[1] = e[1] * inv; nrm[2] = e[2] * inv;
+            return dist;
+        }
+        int jm = 0;
+        double best = S->h[0] - fabs(x[0]);
+        for (int j = 1; j < 3; ++j) { const double g = S->h[j] - fabs(x[j]); if (g < best) { best = g; jm = j; } }
+        const double sg = x[jm] >= 0.0 ? 1.0 : -1.0;
+        nrm[0] = sg * S->ax[jm][0]; nrm[1] = sg * S->ax[jm][1]; nrm[2] = sg * S->ax[jm][2];
+        axpy3(best, nrm, p, cp);
+        return -best;
+    }
+    /* cylinder */
+    const double *u = S->ax[2];
+    const double z = dot3(d, u);
+    double w[3];
+    axpy3(-z, u, d, w);
+    const double rho = sqrt(dot3(w, w));
+    const double dz = fabs(z) - S->h[0], dr = rho - S->rad;
+    const double sz = z >= 0.0 ? 1.0 : -1.0;
+    double rdir[3];
+    if (rho > 0.0) { const double inv = 1.0 / rho; rdir[0] = w[0] * inv; rdir[1] = w[1] * inv; rdir[2] = w[2] * inv; }
+    else { /* on the axis: any radial direction; take the box-like axis 0 of the pose */
+        rdir[0] = S->ax[0][0]; rdir[1] = S->ax[0][1]; rdir[2] = S->ax[0][2];
+    }
+    if (dz <= 0.0 && dr <= 0.0) {
+        if (dr > dz) { nrm[0] = rdir[0]; nrm[1] = rdir[1]; nrm[2] = rdir[2]; axpy3(-dr, nrm, p, cp); return dr; }
+        nrm[0] = sz * u[0]; nrm[1] = sz * u[1]; nrm[2] = sz * u[2];
+        axpy3(-dz, nrm, p, cp);
+        return dz;
+    }
+    const double zc = clampd(z, -S->h[0], S->h[0]);
+    const double rc = rho < S->rad ? rho : S->rad;
+    double tmp[3];
+    axpy3(zc, u, S->c, tmp);
+    axpy3(rc, rdir, tmp, cp);
+    double e[3];
+    sub3(p, cp, e);
+    const double dist = sqrt(dot3(e, e));
+    const double inv = 1.0 / dist;
+    nrm[0] = e[0] * inv; nrm[1] = e[1] * inv; nrm[2] = e[2] * inv;
+    return dist;
+}
+
+/* signed distance between two shapes given as cores; witness = pa(3) pb(3) n(3), n from B to A */
+static double cores_distance(const core_t *A, const core_t *Bc, double *wit, int *iters) {
+    double pa[3], pb[3], n[3];
+    double dc;
+    if (iters) *iters = 0;
+    if (Bc->kind == K_PLANE) {
+        const double *nn = Bc->ax[2];
+        double d[3];
+        sub3(A->c, Bc->c, d);
+        const double hc = dot3(d, nn);
+        const double hw = core_halfwidth(A, nn);
+        const double dist = (hc - hw) - A->margin;
+        if (wit) {
+            double neg[3] = {-nn[0], -nn[1], -nn[2]};
+            core_support(A, neg, pa);
+            axpy3(-A->margin, nn, pa, pa);
+            axpy3(-dist, nn, pa, pb);
+            memcpy(wit, pa, 24); memcpy(wit + 3, pb, 24); memcpy(wit + 6, nn, 24);
+        }
+        return dist;
+    }
+    const int a_ps = (A->kind == K_POINT || A->kind == K_SEG), b_ps = (Bc->kind == K_POINT || Bc->kind == K_SEG);
+    if (a_ps && b_ps) {
+        ps_closest(A, Bc, pa, pb);
+        double e[3];
+        sub3(pa, pb, e);
+        dc = sqrt(dot3(e, e));
+        if (dc > 0.0) { const double inv = 1.0 / dc; n[0] = e[0] * inv; n[1] = e[1] * inv; n[2] = e[2] * inv; }
+        else {
+            double cr[3];
+            cross3(A->ax[2], Bc->ax[2], cr);
+            const double cc = dot3(cr, cr);
+            if (A->kind == K_SEG && Bc->kind == K_SEG && cc > 1e-24) { const double inv = 1.0 / sqrt(cc); n[0] = cr[0] * inv; n[1] = cr[1] * inv; n[2] = cr[2] * inv; }
+            else { n[0] = 1.0; n[1] = 0.0; n[2] = 0.0; }
+        }
+    } else if (A->kind == K_POINT) {
+        double nb[3];
+        dc = point_solid(A->c, Bc, pb, nb);
+        memcpy(pa, A->c, 24);
+        n[0] = nb[0]; n[1] = nb[1]; n[2] = nb[2];
+    } else if (Bc->kind == K_POINT) {
+        double na[3];
+        dc = point_solid(Bc->c, A, pa, na);
+        memcpy(pb, Bc->c, 24);
+        n[0] = -na[0]; n[1] = -na[1]; n[2] = -na[2];
+    } else {
+        double v[3];
+        const int ov = gjk_cores(A, Bc, pa, pb, v, iters);
+        if (!ov) {
+            /* the distance is the norm of GJK's own closest vector; pa/pb only serve as witnesses */
+            dc = sqrt(dot3(v, v));
+            const double inv = 1.0 / dc;
+            n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
+        } else {
+            const double depth = overlap_depth(A, Bc, n);
+            dc = -depth;
+            double neg[3] = {-n[0], -n[1], -n[2]};
+            core_support(A, neg, pa);      /* deepest point of A along the normal */
+            axpy3(dc, n, pa, pb);          /* pb = pa - depth*n */
+        }
+    }
+    const double dist = (dc - A->margin) - Bc->margin;
+    if (wit) {
+        double wa[3], wb[3];
+        axpy3(-A->margin, n, pa, wa);
+        axpy3(Bc->margin, n, pb, wb);
+        memcpy(wit, wa, 24); memcpy(wit + 3, wb, 24); memcpy(wit + 6, n, 24);
+    }
+    return dist;
+}
+
+/* predicate used by validity: is the signed distance below thr?  Decided on the CORE distance against
+ * tc = (thr + mA) + mB so that no square root / iteration is spent once the answer is known. */
+static int cores_collide(const core_t *A, const core_t *Bc, double thr) {
+    if (Bc->kind == K_PLANE) {
+        double d[3];
+        sub3(A->c, Bc->c, d);
+        return (dot3(d, Bc->ax[2]) - core_halfwidth(A, Bc->ax[2])) < (thr + A->margin);
+    }
+    const double tc = (thr + A->margin) + Bc->margin;
+    const int a_ps = (A->kind == K_POINT || A->kind == K_SEG), b_ps = (Bc->kind == K_POINT || Bc->kind == K_SEG);
+    if (a_ps && b_ps) {
+        double pa[3], pb[3], e[3];
+        ps_closest(A, Bc, pa, pb);
+        sub3(pa, pb, e);
+        return sqrt(dot3(e, e)) < tc;
+    }
+    if (A->kind == K_POINT) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
+    if (Bc->kind == K_POINT) { double cp[3], na[3]; return point_solid(Bc->c, A, cp, na) < tc; }
+    return gjk_collides(A, Bc, tc);
+}
+
+double orc_shape_distance(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                          const double *pose_b, const double *param_b, double *witness, int32_t *iters) {
+    xf_t xa, xb;
+    core_t A, Bc;
+    xf_from12(pose_a, &xa); xf_from12(pose_b, &xb);
+    core_from_shape(type_a, &xa, param_a, &A);
+    core_from_shape(type_b, &xb, param_b, &Bc);
+    int it = 0;
+    const double d = cores_distance(&A, &Bc, witness, &it);
+    if (iters) *iters = it;
+    return d;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * per-configuration collision evaluation
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { core_t *world; } scene_cache_t;
+
+static core_t *build_world_cores(const orc_model *m) {
+    core_t *w = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_wshapes > 0 ? m->n_wshapes : 1));
+    for (int i = 0; i < m->n_wshapes; ++i) {
+        xf_t x;
+        xf_from12(m->wshape_pose + 12 * i, &x);
+        core_from_shape(m->wshape_type[i], &x, m->wshape_param + 4 * i, &w[i]);
+    }
+    return w;
+}
+
+/* frames of all joints (topological order), then world cores of all robot shapes */
+static void robot_cores(const orc_model *m, const double *q, xf_t *frames, core_t *rc) {
+    xf_t base;
+    xf_from12(m->base_pose, &base);
+    for (int k = 0; k < m->n_joints; ++k) {
+        const xf_t *par = m->joint_parent[k] < 0 ? &base : &frames[m->joint_parent[k]];
+        joint_apply(m, k, par, q, &frames[k]);
+    }
+    for (int s = 0; s < m->n_rshapes; ++s) {
+        const xf_t *F = m->rshape_frame[s] < 0 ? &base : &frames[m->rshape_frame[s]];
+        xf_t loc, W;
+        xf_from12(m->rshape_local + 12 * s, &loc);
+        xf_mul(F, loc.R, loc.t, &W);
+        core_from_shape(m->rshape_type[s], &W, m->rshape_param + 4 * s, &rc[s]);
+    }
+}
+
+static int pair_hit(const orc_model *m, const core_t *rc, const core_t *wc, int p, double thr) {
+    const int a = m->pair_a[p], b = m->pair_b[p];
+    return cores_collide(&rc[a], b < m->n_rshapes ? &rc[b] : &wc[b - m->n_rshapes], thr);
+}
+
+static double pair_eval(const orc_model *m, const core_t *rc, const core_t *wc, int p, double *wit) {
+    const int a = m->pair_a[p], b = m->pair_b[p];
+    const core_t *A = &rc[a];
+    const core_t *Bc = b < m->n_rshapes ? &rc[b] : &wc[b - m->n_rshapes];
+    return cores_distance(A, Bc, wit, NULL);
+}
+
+int orc_pair_distances(const orc_model *m, const double *q, int64_t B, double *dist, double *witness) {
+    core_t *wc = build_world_cores(m);
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
+    core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
+    for (int64_t b = 0; b < B; ++b) {
+        robot_cores(m, q + b * m->n_q, frames, rc);
+        for (int p = 0; p < m->n_pairs; ++p)
+            dist[b * m->n_pairs + p] = pair_eval(m, rc, wc, p, witness ? witness + (b * m->n_pairs + p) * 9 : NULL);
+    }
+    free(wc); free(frames); free(rc);
+    return 0;
+}
+
+int orc_closest(const orc_model *m, const double *q, int64_t B, double *min_dist, int32_t *argmin) {
+    core_t *wc = build_world_cores(m);
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
+    core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
+    for (int64_t b = 0; b < B; ++b) {
+        robot_cores(m, q + b * m->n_q, frames, rc);
+        double best = INFINITY;
+        int bi = -1;
+        for (int p = 0; p < m->n_pairs; ++p) {
+            const double d = pair_eval(m, rc, wc, p, NULL);
+            if (d < best) { best = d; bi = p; }
+        }
+        min_dist[b] = best;
+        if (argmin) argmin[b] = bi;
+    }
+    free(wc); free(frames); free(rc);
+    return 0;
+}
+
+typedef struct {
+    const orc_model *m; const double *q; int64_t b0, b1; double thr; uint8_t *mask; const core_t *wc;
+} vjob_t;
+
+static void *validity_worker(void *arg) {
+    vjob_t *j = (vjob_t *)arg;
+    const orc_model *m = j->m;
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
+    core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
+    for (int64_t b = j->b0; b < j->b1; ++b) {
+        robot_cores(m, j->q + b * m->n_q, frames, rc);
+        uint8_t hit = 0;
+        for (int p = 0; p < m->n_pairs && !hit; ++p)
+            if (pair_hit(m, rc, j->wc, p, j->thr)) hit = 1;
+        j->mask[b] = hit;
+    }
+    free(frames); free(rc);
+    return NULL;
+}
+
+int orc_validity(const orc_model *m, const double *q, int64_t B, double threshold, uint8_t *mask, int32_t nthreads) {
+    core_t *wc = build_world_cores(m);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    vjob_t jobs[256];
+    const int64_t chunk = (B + nthreads - 1) / nthreads;
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t b0 = t * chunk, b1 = (b0 + chunk < B) ? b0 + chunk : B;
+        if (b0 >= B) break;
+        jobs[t] = (vjob_t){m, q, b0, b1, threshold, mask, wc};
+        if (nthreads == 1) validity_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, validity_worker, &jobs[t]);
+        ++started;
+    }
+    if (nthreads > 1) for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    free(wc);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * DiscreteConnector (connectors.py:57-100).  T = arange(0, T_f, res/d) then T_f appended;
+ * arange length = ceil(T_f / step), values i*step; traj(t) = (1-t)*start + t*goal (unfused).
+ * ---------------------------------------------------------------------------------------------- */
+static double edge_length(int32_t n_q, const double *s, const double *g) {
+    double acc = 0.0;
+    for (int i = 0; i < n_q; ++i) { const double df = g[i] - s[i]; acc = FMA(df, df, acc); }
+    return sqrt(acc);
+}
+static void edge_point(int32_t n_q, const double *s, const double *g, double t, double *o) {
+    const double omt = 1.0 - t;
+    for (int i = 0; i < n_q; ++i) { const double a = omt * s[i]; const double b = t * g[i]; o[i] = a + b; }
+}
+/* returns n = len(arange) (so n+1 samples) or -1 for the degenerate edge; writes T_f and step */
+static int64_t edge_plan(double d, double resolution, double max_distance, int mode, double *Tf, double *step) {
+    if (!(d > (double)FLT_EPSILON)) return -1;
+    *Tf = (mode == 1 && d > max_distance) ? max_distance / d : 1.0;
+    *step = resolution / d;
+    const double len = ceil(*Tf / *step);
+    return len > 0.0 ? (int64_t)len : 0;
+}
+
+int orc_edge_samples(int32_t n_q, const double *start, const double *goal, double dist, double resolution,
+                     double max_distance, int32_t mode, double *out, int32_t max_samples) {
+    const double d = dist >= 0.0 ? dist : edge_length(n_q, start, goal);
+    double Tf, step;
+    const int64_t n = edge_plan(d, resolution, max_distance, mode, &Tf, &step);
+    if (n < 0) return 0;
+    int cnt = 0;
+    for (int64_t i = 0; i <= n && cnt < max_samples; ++i, ++cnt)
+        edge_point(n_q, start, goal, i < n ? (double)i * step : Tf, out + (size_t)cnt * n_q);
+    return (int)(n + 1);
+}
+
+typedef struct {
+    const orc_model *m; const double *starts, *goals, *dist; int64_t e0, e1; double res, maxd, thr; int mode;
+    uint8_t *valid; double *end; int32_t *ns; const core_t *wc;
+} ejob_t;
+
+static void *edge_worker(void *arg) {
+    ejob_t *j = (ejob_t *)arg;
+    const orc_model *m = j->m;
+    const int nq = m->n_q;
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
+    core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
+    double *qs = (double *)malloc(sizeof(double) * (size_t)nq);
+    for (int64_t e = j->e0; e < j->e1; ++e) {
+        const double *s = j->starts + e * nq, *g = j->goals + e * nq;
+        const double d = j->dist ? j->dist[e] : edge_length(nq, s, g);
+        double Tf, step;
+        const int64_t n = edge_plan(d, j->res, j->maxd, j->mode, &Tf, &step);
+        if (n < 0) {
+            j->valid[e] = 0;
+            if (j->ns) j->ns[e] = 0;
+            if (j->end) for (int i = 0; i < nq; ++i) j->end[e * nq + i] = NAN;
+            continue;
+        }
+        uint8_t ok = 1;
+        for (int64_t i = 0; i <= n && ok; ++i) {
+            edge_point(nq, s, g, i < n ? (double)i * step : Tf, qs);
+            robot_cores(m, qs, frames, rc);
+            for (int p = 0; p < m->n_pairs; ++p)
+                if (pair_hit(m, rc, j->wc, p, j->thr)) { ok = 0; break; }
+        }
+        j->valid[e] = ok;
+        if (j->ns) j->ns[e] = (int32_t)(n + 1);
+        if (j->end) {
+            if (j->mode == 0) for (int i = 0; i < nq; ++i) j->end[e * nq + i] = g[i];
+            else edge_point(nq, s, g, Tf, j->end + e * nq);
+        }
+    }
+    free(frames); free(rc); free(qs);
+    return NULL;
+}
+
+int orc_edge_validity(const orc_model *m, const double *starts, const double *goals, const double *dist,
+                      int64_t E, double resolution, double max_distance, int32_t mode, double threshold,
+                      uint8_t *valid, double *end, int32_t *n_samples, int32_t nthreads) {
+    core_t *wc = build_world_cores(m);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    ejob_t jobs[256];
+    const int64_t chunk = (E + nthreads - 1) / nthreads;
+    int started = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        const int64_t e0 = t * chunk, e1 = (e0 + chunk < E) ? e0 + chunk : E;
+        if (e0 >= E) break;
+        jobs[t] = (ejob_t){m, starts, goals, dist, e0, e1, resolution, max_distance, threshold, mode, valid, end, n_samples, wc};
+        if (nthreads == 1) edge_worker(&jobs[t]);
+        else pthread_create(&th[t], NULL, edge_worker, &jobs[t]);
+        ++started;
+    }
+    if (nthreads > 1) for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    free(wc);
+    return 0;
+}
+
+int orc_shape_collides(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                       const double *pose_b, const double *param_b, double threshold) {
+    xf_t xa, xb;
+    core_t A, Bc;
+    xf_from12(pose_a, &xa); xf_from12(pose_b, &xb);
+    core_from_shape(type_a, &xa, param_a, &A);
+    core_from_shape(type_b, &xb, param_b, &Bc);
+    return cores_collide(&A, &Bc, threshold);
+}
