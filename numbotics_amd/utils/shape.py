@@ -21,7 +21,7 @@ class Shape(Enum):
 
 _SHAPE_KWARGS = frozenset({
     'offset', 'half_extents', 'radius', 'height', 'width', 'normal', 'filename', 'color',
-    'mesh_scale', 'auto_center', 'convex_decomposition',
+    'mesh_scale', 'auto_center', 'convex_decomposition', 'collision_margin',
 })
 
 

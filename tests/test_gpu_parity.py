@@ -1,0 +1,257 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle, bit for bit, and against the
+reference-generated golden vectors.  Needs a real MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.cpu_oracle import Oracle, sincos, sqrt_div
+from numbotics_amd.scenes import build_scene, sample_q
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+
+
+def assert_bitwise(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    same = (bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        idx = np.argwhere(~same)[0]
+        raise AssertionError(f"{what}: {(~same).sum()} of {same.size} values differ; first at {tuple(idx)}: "
+                             f"{a[tuple(idx)]!r} vs {b[tuple(idx)]!r}; max abs diff {np.nanmax(np.abs(a - b))}")
+
+
+def test_arithmetic_contract(torch_cuda):
+    """sincos / sqrt / divide on the device round exactly like the host oracle."""
+    from numbotics_amd.engine import selftest_math
+    rng = np.random.default_rng(0)
+    a = np.concatenate([rng.uniform(-10, 10, 200000), rng.uniform(0, 1e-3, 50000), rng.uniform(-1e6, 1e6, 50000),
+                        np.array([0.0, -0.0, 1.0, np.pi, np.pi / 2, 1e-300, 1e300, np.inf, np.nan, 4e9])])
+    b = rng.uniform(-3, 3, a.size)
+    b[b == 0] = 1.0
+    s, c, sq, dv = selftest_math(a, b)
+    so, co = sincos(a)
+    with np.errstate(invalid="ignore"):
+        sqo, dvo = sqrt_div(a, b)
+    assert_bitwise(s, so, "sin")
+    assert_bitwise(c, co, "cos")
+    assert_bitwise(sq, sqo, "sqrt")
+    assert_bitwise(dv, dvo, "div")
+
+
+def test_fk_bitwise_and_golden(kinova, g3, golden_meta, torch_cuda):
+    arm, chain, _ = kinova
+    orc = Oracle(arm._kin)
+    q = g3["g3_q"]
+    for f in golden_meta["g3_frames"]:
+        T = arm.forward_kinematics(q, f)
+        assert_bitwise(T, orc.fk(q, f), f"fk {f}")
+    for f in golden_meta["g3_trailing_fixed_frames"]:
+        ref = g3[f"g3_fk_{f}"]
+        T = arm.forward_kinematics(q[:ref.shape[0]], f)
+        assert np.abs(T - ref).max() < 1e-12          # north-star bar: 1e-6
+    # shapes and options, as the reference returns them
+    assert arm.forward_kinematics(q[0], "tool_frame").shape == (4, 4)
+    assert np.abs(arm.forward_kinematics(q[0], "tool_frame") - g3["g3_fk_tool_frame_1d"]).max() < 1e-12
+    T3 = arm.forward_kinematics(q[:12].reshape(3, 4, 7), "tool_frame")
+    assert T3.shape == (3, 4, 4, 4) and np.abs(T3 - g3["g3_fk_tool_frame_3d"]).max() < 1e-12
+    lp, lpb = g3["g3_local_pose"], g3["g3_local_pose_batch"]
+    assert np.abs(arm.forward_kinematics(q[:128], "tool_frame", local_pose=lp) - g3["g3_fk_tool_frame_local"]).max() < 1e-12
+    assert np.abs(arm.forward_kinematics(q[:128], "tool_frame", local_pose=lpb) - g3["g3_fk_tool_frame_local_batch"]).max() < 1e-12
+    # ragged sizes around the 64-lane block
+    for B in (1, 63, 64, 65, 127, 129):
+        assert_bitwise(arm.forward_kinematics(q[:B], "gripper"), orc.fk(q[:B], "gripper"), f"fk B={B}")
+    # torch in -> torch out, stays on the device
+    tq = torch_cuda.from_numpy(q).cuda()
+    Tt = arm.forward_kinematics(tq, "tool_frame")
+    assert Tt.is_cuda and Tt.shape == (1024, 4, 4)
+    assert_bitwise(Tt.cpu().numpy(), orc.fk(q, "tool_frame"), "fk torch")
+
+
+def test_jacobian_bitwise_and_golden(kinova, g3, golden_meta, torch_cuda):
+    arm, chain, _ = kinova
+    orc = Oracle(arm._kin)
+    q = g3["g3_q"]
+    for f in golden_meta["g3_frames"]:
+        assert_bitwise(arm.jacobian(q[:200], f), orc.jacobian(q[:200], f), f"jac {f}")
+    for f in golden_meta["g3_trailing_fixed_frames"]:
+        jr = g3[f"g3_jac_{f}"]
+        assert np.abs(arm.jacobian(q[:jr.shape[0]], f, global_pose=None) - jr).max() < 1e-12
+    lp, gp = g3["g3_local_pose"], g3["g3_global_pose"]
+    assert np.abs(arm.jacobian(q[:128], "tool_frame", local_pose=lp) - g3["g3_jac_tool_frame_local"]).max() < 1e-12
+    assert np.abs(arm.jacobian(q[:128], "tool_frame", global_pose=gp) - g3["g3_jac_tool_frame_global"]).max() < 1e-12
+    assert arm.jacobian(q[0], "tool_frame").shape == (6, 7)                       # default global_pose=False (Q2)
+    assert np.array_equal(arm.jacobian(q[:4], "base_link"), np.zeros((4, 6, 7)))  # arm.py:455-457
+
+
+@pytest.mark.parametrize("scene", ["c2", "c3"])
+def test_validity_mask_bitwise(fresh_world, scene, torch_cuda):
+    arm, chain, obs = build_scene(scene)
+    sm = arm.scene_model()
+    orc = Oracle(sm)
+    q = sample_q(chain, 20000, seed=2)
+    for thr in (0.0, 1e-6, 0.02, -0.005):
+        mask = arm.in_collision(q, thr)
+        ref = orc.validity(q, thr)
+        assert mask.dtype == bool and mask.shape == (20000,)
+        assert np.array_equal(mask, ref), (scene, thr, int((mask != ref).sum()))
+    assert 0.01 < orc.validity(q, 0.0).mean() < 0.9
+    # packed bit mask == bytes
+    _, dev = arm._scene_device()
+    words = dev.validity(q, 0.0, packed=True)
+    unpacked = ((words.view(np.uint64)[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).reshape(-1)
+    assert np.array_equal(unpacked[:20000], orc.validity(q, 0.0)) and not unpacked[20000:].any()
+    # scalar contract
+    assert isinstance(arm.in_collision(q[0]), bool) and arm.in_collision(q[0]) == bool(ref_first(orc, q[0]))
+    with pytest.raises(ValueError):
+        arm.in_collision(q[:, :6])
+    for B in (1, 63, 64, 65, 130):
+        assert np.array_equal(arm.in_collision(q[:B]), orc.validity(q[:B]))
+
+
+def ref_first(orc, q0):
+    return orc.validity(q0.reshape(1, -1))[0]
+
+
+@pytest.mark.parametrize("scene", ["c2", "c3"])
+def test_distances_bitwise(fresh_world, scene, torch_cuda):
+    arm, chain, obs = build_scene(scene)
+    sm = arm.scene_model()
+    orc = Oracle(sm)
+    q = sample_q(chain, 3000, seed=3)
+    D = arm.pair_distances(q)
+    Dref = orc.pair_distances(q)
+    assert_bitwise(D, Dref, "pair distances")
+    dmin, idx = arm.closest_distance(q)
+    dref, iref = orc.closest(q)
+    assert_bitwise(dmin, dref, "closest distance")
+    assert np.array_equal(idx, iref)
+    # validity predicate == (closest distance < thr) away from the threshold
+    for thr in (0.0, 0.01):
+        assert np.array_equal(arm.in_collision(q, thr), dmin < thr)
+    # Proximity records of the scalar API
+    _, dev = arm._scene_device()
+    Dw, W = dev.pair_distances(q[:300], witness=True)
+    Dr, Wr = orc.pair_distances(q[:300], witness=True)
+    assert_bitwise(Dw, Dr, "distances (witness kernel)")
+    assert_bitwise(W, Wr, "witness points")
+    prox = arm.collisions(q[0])
+    assert len(prox) == sm.n_pairs
+    best = arm.closest_to(q[0])
+    assert best.distance == dref[0]
+    with pytest.raises(ValueError):
+        arm.collisions(q[:2])
+
+
+def test_shape_zoo_distances(fresh_world, torch_cuda):
+    """Every primitive pair class, incl. capsule / sphere / cylinder / plane obstacles and margins."""
+    from numbotics_amd.physics import GraphChain, Cube, Cuboid, Sphere, Capsule, Cylinder, Plane
+    from numbotics_amd.robots import Arm
+    from conftest import URDF
+    chain = GraphChain.from_urdf(URDF)
+    arm = Arm(chain)
+    rng = np.random.default_rng(9)
+    from geom_truth import random_pose
+    obs = [Cube(0.0, 0.2, position=np.array([0.6, 0.1, 0.3])),
+           Cuboid(0.0, np.array([0.1, 0.3, 0.05]), pose=random_pose(rng, 0.7)),
+           Sphere(0.0, 0.15, position=np.array([-0.5, 0.3, 0.6])),
+           Capsule(0.0, 0.08, 0.4, pose=random_pose(rng, 0.7)),
+           Cylinder(0.0, 0.12, 0.3, pose=random_pose(rng, 0.7)),
+           Plane(0.0, np.array([0.0, 0.0, 1.0]), position=np.array([0.0, 0.0, -0.05])),
+           Cuboid(0.0, np.array([0.2, 0.2, 0.2]), position=np.array([0.0, -0.7, 0.5]), collision_margin=0.04)]
+    sm = arm.scene_model()
+    assert sm.n_wshapes == 7
+    orc = Oracle(sm)
+    q = sample_q(chain, 2000, seed=5)
+    assert_bitwise(arm.pair_distances(q), orc.pair_distances(q), "zoo distances")
+    for thr in (0.0, 0.03):
+        assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr))
+
+
+@pytest.mark.parametrize("mode", ["connect", "steer"])
+def test_edge_validity(fresh_world, mode, torch_cuda):
+    from numbotics_amd.planning.sampling_based import ConnectorParams, DiscreteConnector
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    rng = np.random.default_rng(6)
+    lim = chain.joint_limits
+    E = 300
+    s = rng.uniform(lim[:, 0], lim[:, 1], (E, 7))
+    g = s + rng.normal(scale=0.6, size=(E, 7))
+    s[0] = g[0]                                  # degenerate edge -> invalid
+    for res, maxd in ((0.05, np.pi), (0.01, 1.0)):
+        conn = DiscreteConnector(ConnectorParams(resolution=res, max_distance=maxd, arm=arm))
+        _, dev = arm._scene_device()
+        ok, end, ns = dev.edge_validity(s, g, res, maxd, mode=mode)
+        okr, endr, nsr = orc.edge_validity(s, g, res, maxd, mode=mode)
+        assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
+        assert_bitwise(end, endr, "edge end states")
+        assert not ok[0] and ns[0] == 0
+        assert 0 < ok.mean() < 1
+        # scalar contract: goal copy / traj(T_f) / None
+        for e in range(12):
+            r = getattr(conn, mode)(s[e], g[e])
+            if okr[e]:
+                assert r is not None and np.array_equal(r, endr[e])
+            else:
+                assert r is None
+
+
+def test_edge_matches_per_sample_walk(fresh_world, torch_cuda):
+    """The batched edge kernel equals the reference algorithm run sample by sample with the scalar
+    validity checker `not arm.in_collision(q)` (README.md:107)."""
+    from numbotics_amd.planning.sampling_based import ConnectorParams, DiscreteConnector
+    arm, chain, obs = build_scene("c2")
+    rng = np.random.default_rng(8)
+    lim = chain.joint_limits
+    walk = DiscreteConnector(ConnectorParams(resolution=0.1, max_distance=np.pi,
+                                             validity_checker=lambda q: not arm.in_collision(q)))
+    fast = DiscreteConnector(ConnectorParams(resolution=0.1, max_distance=np.pi, arm=arm))
+    n_none = 0
+    for _ in range(25):
+        a, b = rng.uniform(lim[:, 0], lim[:, 1]), rng.uniform(lim[:, 0], lim[:, 1])
+        for mode in ("connect", "steer"):
+            r1, r2 = getattr(walk, mode)(a, b), getattr(fast, mode)(a, b)
+            assert (r1 is None) == (r2 is None)
+            if r1 is not None:
+                assert np.array_equal(r1, r2)
+            else:
+                n_none += 1
+    assert n_none > 0
+
+
+def test_full_size_properties(fresh_world, torch_cuda):
+    """BASELINE config 2 at full size (1e6 q): size-independent properties + oracle on a slice."""
+    torch = torch_cuda
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    B = 1_000_000
+    q = sample_q(chain, B, seed=1)
+    tq = torch.from_numpy(q).cuda()
+    m1 = arm.in_collision(tq)
+    assert m1.is_cuda and m1.dtype == torch.bool and m1.shape == (B,)
+    m1 = m1.cpu().numpy()
+    # idempotence / determinism
+    assert np.array_equal(m1, arm.in_collision(tq).cpu().numpy())
+    # sharding invariance: any split point gives the same bits (what the multi-GPU path relies on)
+    cut = 333_333
+    m2 = np.concatenate([arm.in_collision(tq[:cut]).cpu().numpy(), arm.in_collision(tq[cut:]).cpu().numpy()])
+    assert np.array_equal(m1, m2)
+    # permutation equivariance
+    perm = np.random.default_rng(0).permutation(B)
+    assert np.array_equal(arm.in_collision(tq[torch.from_numpy(perm).cuda()]).cpu().numpy(), m1[perm])
+    # oracle on a 50k slice spread over the batch
+    sl = np.arange(0, B, 20)
+    assert np.array_equal(m1[sl], orc.validity(q[sl], nthreads=8))
+    # threshold monotonicity
+    m_hi = arm.in_collision(tq, 0.05).cpu().numpy()
+    assert (m_hi | ~m1).all() and m_hi.sum() > m1.sum()
