@@ -164,7 +164,7 @@ class Arm(Robot):
             return None
         if not a_in:
             link_a, link_b = link_b, link_a
-            b_in = True
+            b_in = False
         return link_a, link_b, b_in
 
     @staticmethod

@@ -1,0 +1,86 @@
+"""The N > 1 path on CPU: world_size-2 gloo.  Sharding + all-gather of the packed validity words; the
+per-shard compute is stood in for by the CPU oracle (the product's device call cannot run here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, total, q, expect_words, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from numbotics_amd.physics import World
+        from numbotics_amd.scenes import build_scene
+        from numbotics_amd.parallel import sharded_validity, shard_bounds, unpack_mask
+        from oracle.cpu_oracle import Oracle
+        World()
+        arm, chain, obs = build_scene("c2")
+        orc = Oracle(arm.scene_model())
+
+        def words_fn(q_shard):
+            m = orc.validity(q_shard)
+            pad = (-len(m)) % 64
+            bits = np.concatenate([m, np.zeros(pad, dtype=bool)]).reshape(-1, 64)
+            w = (bits.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+            return w.view(np.int64)
+        words = sharded_validity(words_fn, q, total)
+        lo, hi = shard_bounds(total, world, rank)
+        ok = bool(np.array_equal(words.numpy().view(np.uint64), expect_words))
+        ok = ok and bool(np.array_equal(unpack_mask(words.numpy(), total), unpack_mask(expect_words, total)))
+        ret[rank] = (ok, lo, hi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [1000, 128, 130])
+def test_sharded_mask_allgather_gloo(total, fresh_world):
+    from numbotics_amd.scenes import build_scene, sample_q
+    from numbotics_amd.parallel import shard_bounds, shard_words
+    from oracle.cpu_oracle import Oracle
+    arm, chain, obs = build_scene("c2")
+    q = sample_q(chain, total, seed=4)
+    full = Oracle(arm.scene_model()).validity(q)
+    world = 2
+    nw = shard_words(total, world)
+    per = nw * 64
+    padded = np.zeros(world * per, dtype=bool)
+    for r in range(world):
+        lo, hi = shard_bounds(total, world, r)
+        padded[r * per:r * per + (hi - lo)] = full[lo:hi]
+    expect = (padded.reshape(-1, 64).astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)
+    # with equal 64-aligned shards the gathered words ARE the global mask
+    if total % (64 * world) == 0:
+        assert np.array_equal(padded[:total], full)
+    port = 29500 + (os.getpid() + total) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, total, q, expect, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        ok, lo, hi = ret[r]
+        assert ok, f"rank {r} gathered a different mask"
+    assert ret[0][1] == 0 and ret[world - 1][2] == total
+
+
+def test_shard_bounds_cover_and_align():
+    from numbotics_amd.parallel import shard_bounds
+    for total in (0, 1, 63, 64, 65, 1000, 10_000_000):
+        for world in (1, 2, 4, 8):
+            prev = 0
+            for r in range(world):
+                lo, hi = shard_bounds(total, world, r)
+                assert lo == prev and lo % 64 == 0 or lo == total
+                assert hi >= lo
+                prev = hi
+            assert prev == total
+    lo, hi = shard_bounds(10_000_000, 8, 3)
+    assert hi - lo == 1_250_048 - 48 or (hi - lo) % 64 == 0
