@@ -112,7 +112,7 @@ def main():
     w = words.cpu().numpy().view(np.uint64)
     bits = ((w[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).reshape(-1)[:hi - lo]
     sl = np.arange(0, hi - lo, max(1, (hi - lo) // 20000))
-    parity_ok = bool(np.array_equal(bits[sl], orc.validity(q_host[sl], 0.0, nthreads=os.cpu_count() or 1)))
+    parity_ok = bool(np.array_equal(bits[sl], orc.validity(q_host[sl], 0.0, nthreads=8)))
     coll_frac = float(bits.mean())
 
     # ---- roofline of the dominant kernel (validity) ---------------------------------------------------
@@ -143,7 +143,8 @@ def main():
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample ---------------------
     cpu = None
     if not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
+        # the box's CPU share for one GPU is 16 cores (gpurun guidance); never more threads than allowed CPUs
+        cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
         n_s = min(hi - lo, 1_000_000)
         t_start = time.perf_counter()
         reps_cpu = 0

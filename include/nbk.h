@@ -116,6 +116,17 @@ int32_t nbk_jacobian_batch(const nbk_model *m, const double *q, int64_t B, const
  */
 int32_t nbk_validity_batch(const nbk_model *m, const double *q, int64_t B, double threshold,
                            uint64_t *mask_bits, uint8_t *mask_bytes, void *stream);
+/*
+ * Same, with caller-owned scratch.  Large batches run as a broadphase kernel that appends the surviving
+ * (configuration, pair) items to a queue in `workspace`, followed by a dense narrowphase kernel.
+ * nbk_validity_workspace_bytes(m, B) gives the size needed (0 = the fused single-kernel path is used).
+ * nbk_validity_batch itself keeps one internal workspace per descriptor (grown with hipMalloc on demand,
+ * calls on the same descriptor serialise on it): use this variant for concurrent streams or graph capture.
+ */
+int64_t nbk_validity_workspace_bytes(const nbk_model *m, int64_t B);
+int32_t nbk_validity_batch_ws(const nbk_model *m, const double *q, int64_t B, double threshold,
+                              uint64_t *mask_bits, uint8_t *mask_bytes, void *workspace,
+                              int64_t workspace_bytes, void *stream);
 
 /*
  * Batched Arm.closest_to (arm.py:599-600): min signed distance and the index of the pair attaining it

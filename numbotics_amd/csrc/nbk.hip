@@ -13,9 +13,12 @@
 // No MFMA: this is a transform chain + branchy narrowphase, not a contraction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/nbk.h"
@@ -41,12 +44,22 @@ struct DevModel {
     const int* rs_kind;           // [S] core kind, in frame order
     const int* rs_row;            // [S] first LDS row
     const double* rs_local;       // [S][12]
-    const double* rs_core;        // [S][5] h0 h1 h2 rad margin
+    const double* rs_core;        // [S][6] h0 h1 h2 rad margin rho
     const int* ws_kind;           // [W]
-    const double* ws_core;        // [W][17] c(3) ax(9: ax0 ax1 ax2) h(3) rad margin
+    const double* ws_core;        // [W][18] c(3) ax(9: ax0 ax1 ax2) h(3) rad margin rho
     const int* pair_a;            // [P] index into rs_* (frame order)
     const int* pair_b;            // [P] < S robot (frame order), else S + world
     const int* pair_user;         // [P] index of this pair in the caller's pair list
+    // validity tables: pairs sorted by class (0 plane, 1 closed form, 2 GJK); shape refs: >= 0 robot shape
+    // (frame order), < 0 world shape ~ref
+    const int* vp_tab;            // [P][4] refA, refB (user order), class, pad
+    const int* vp_canon;          // [P][2] the two refs in canonical (kind-ascending) order
+    const double* vp_cst;         // [P][4] mA, mB, rhoA, rhoB (user order)
+    const double* ws_center;      // [W][3]
+    int n_plane_pairs, n_closed_pairs;   // class boundaries inside the sorted tables
+    const unsigned* rs_mask;      // [S] joints on the path from the base to the shape's frame (bit k = joint k)
+    const int* bp_tab;            // [P][4] broadphase refs: LDS centre row of A, centre row of B or ~world index, flags (1 = B is a world box), pad
+    int dbg;                              // ablation switches for profiling builds (NBK_ABLATE env): 1 = no narrowphase, 2 = no pair loop
 };
 
 }  // namespace nbk
@@ -59,6 +72,10 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
+    // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
+    void* ws;
+    size_t ws_bytes;
+    std::mutex mu;
 };
 
 namespace nbk {
@@ -301,9 +318,9 @@ NBK_DEV void sweep_and_park(const DevModel& m, double* lds_q, double* lds_s, dou
 
 NBK_DEV void load_rcore(const DevModel& m, const double* lds_s, int s, int lane, Core& o) {
     const double* rows = lds_s + m.rs_row[s] * WAVE + lane;
-    const double* cc = m.rs_core + 5 * s;
+    const double* cc = m.rs_core + 6 * s;
     o.kind = m.rs_kind[s];
-    o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4];
+    o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4]; o.rho = cc[5];
     o.c[0] = rows[0]; o.c[1] = rows[WAVE]; o.c[2] = rows[2 * WAVE];
     if (o.kind == K_SEG || o.kind == K_CYL) {
         o.ax[2][0] = rows[3 * WAVE]; o.ax[2][1] = rows[4 * WAVE]; o.ax[2][2] = rows[5 * WAVE];
@@ -316,12 +333,12 @@ NBK_DEV void load_rcore(const DevModel& m, const double* lds_s, int s, int lane,
 }
 
 NBK_DEV void load_wcore(const DevModel& m, int w, Core& o) {
-    const double* cc = m.ws_core + 17 * w;
+    const double* cc = m.ws_core + 18 * w;
     o.kind = m.ws_kind[w];
     o.c[0] = cc[0]; o.c[1] = cc[1]; o.c[2] = cc[2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { o.ax[j][0] = cc[3 + 3 * j]; o.ax[j][1] = cc[4 + 3 * j]; o.ax[j][2] = cc[5 + 3 * j]; }
-    o.h[0] = cc[12]; o.h[1] = cc[13]; o.h[2] = cc[14]; o.rad = cc[15]; o.margin = cc[16];
+    o.h[0] = cc[12]; o.h[1] = cc[13]; o.h[2] = cc[14]; o.rad = cc[15]; o.margin = cc[16]; o.rho = cc[17];
 }
 
 NBK_DEV void load_pair(const DevModel& m, const double* lds_s, int p, int lane, Core& A, Core& Bc) {
@@ -331,19 +348,124 @@ NBK_DEV void load_pair(const DevModel& m, const double* lds_s, int p, int lane, 
     else load_wcore(m, b - m.n_rshapes, Bc);
 }
 
-// any allowed pair below thr?  (lane-local; the caller ballots)
-NBK_DEV bool lane_collides(const DevModel& m, const double* lds_s, int lane, double thr, bool active) {
-    bool hit = false;
-    for (int p = 0; p < m.n_pairs; ++p) {
-        // a lane that already has its answer idles; the wave leaves when every lane is done
-        if (__builtin_amdgcn_ballot_w64(active && !hit) == 0ull) break;
-        if (active && !hit) {
-            Core A, Bc;
-            load_pair(m, lds_s, p, lane, A, Bc);
-            if (cores_collide(A, Bc, thr)) hit = true;
+// ---- validity: wavefront broadphase -> compacted narrowphase -------------------------------------------
+// Phase A (dense, uniform): every lane runs the bounding-sphere test of every pair on ITS configuration;
+//   plane pairs and closed-form pairs that survive are decided on the spot; surviving GJK pairs are appended
+//   to a wave-shared LDS queue as (source lane, pair) items with a ballot + prefix count.
+// Phase B (dense again): the queue is drained 64 items at a time -- lane i evaluates item i, reading the
+//   cores of the SOURCE lane's configuration out of the [component][lane] LDS rows -- and raises the source
+//   lane's hit flag.  On the benchmark scene ~2 % of the (configuration, pair) items survive phase A, so the
+//   branchy GJK runs on full waves instead of on a few scattered lanes per pair.
+constexpr int QUEUE_CAP = 512;                  // items; flushed whenever fewer than 64 slots are left
+constexpr int VALIDITY_LDS_EXTRA = QUEUE_CAP * 4 + WAVE * 4;
+
+// core of shape `ref` for the configuration parked in LDS column `col` (ref / col may differ per lane)
+NBK_DEV void load_core_any(const DevModel& m, const double* lds_s, int ref, int col, Core& o) {
+    if (ref >= 0) {
+        const double* rows = lds_s + m.rs_row[ref] * WAVE + col;
+        const double* cc = m.rs_core + 6 * ref;
+        o.kind = m.rs_kind[ref];
+        o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4]; o.rho = cc[5];
+        o.c[0] = rows[0]; o.c[1] = rows[WAVE]; o.c[2] = rows[2 * WAVE];
+        if (o.kind == K_SEG || o.kind == K_CYL) {
+            o.ax[2][0] = rows[3 * WAVE]; o.ax[2][1] = rows[4 * WAVE]; o.ax[2][2] = rows[5 * WAVE];
+        } else if (o.kind == K_BOX) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                o.ax[j][0] = rows[(3 + 3 * j) * WAVE]; o.ax[j][1] = rows[(4 + 3 * j) * WAVE]; o.ax[j][2] = rows[(5 + 3 * j) * WAVE];
+            }
+        }
+    } else {
+        load_wcore(m, ~ref, o);
+    }
+}
+
+NBK_DEV void drain_queue(const DevModel& m, const double* lds_s, const unsigned* queue, int qn, unsigned* lds_hit,
+                         int lane, double thr) {
+    __syncthreads();            // one wave per workgroup: orders the queue / flag writes before the reads below
+    if (m.dbg & 1) qn = 0;
+    for (int base = 0; base < qn; base += WAVE) {
+        const int i = base + lane;
+        if (i < qn) {
+            const unsigned item = queue[i];
+            const int src = (int)(item & 63u);
+            const int p = (int)(item >> 6);
+            if (lds_hit[src] == 0u) {
+                const double* cst = m.vp_cst + 4 * p;
+                const double tc = (thr + cst[0]) + cst[1];
+                Core A, Bc;
+                load_core_any(m, lds_s, m.vp_canon[2 * p], src, A);
+                load_core_any(m, lds_s, m.vp_canon[2 * p + 1], src, Bc);
+                if (cores_collide_exact(A, Bc, tc)) lds_hit[src] = 1u;
+            }
         }
     }
-    return hit;
+}
+
+// returns this lane's in-collision flag.  lds_x: QUEUE_CAP queue words followed by 64 hit flags.
+NBK_DEV bool wave_collides(const DevModel& m, const double* lds_s, unsigned* lds_x, int lane, double thr, bool active) {
+    unsigned* queue = lds_x;
+    unsigned* lds_hit = lds_x + QUEUE_CAP;
+    lds_hit[lane] = 0u;
+    bool hit = false;
+    int qn = 0;                                       // wave-uniform
+    const int np = (m.dbg & 2) ? 0 : m.n_pairs;
+    for (int p = 0; p < np; ++p) {
+        const int* tab = m.vp_tab + 4 * p;
+        const int refA = tab[0], refB = tab[1];
+        if (p < m.n_plane_pairs) {
+            if (active && !hit) {
+                Core A, Pl;
+                load_core_any(m, lds_s, refA, lane, A);
+                load_wcore(m, ~refB, Pl);
+                if (plane_collides(A, Pl, thr, m.vp_cst[4 * p + 2])) hit = true;
+            }
+            continue;
+        }
+        const double* cst = m.vp_cst + 4 * p;
+        const double tc = (thr + cst[0]) + cst[1];
+        const double rs = (tc + cst[2]) + cst[3];
+        if (!(rs > 0.0)) continue;                    // uniform: the spheres can never be that close
+        // centres: robot shapes from this lane's LDS column, world shapes from the scalar table
+        const double* ra = lds_s + m.rs_row[refA] * WAVE + lane;
+        double dl[3];
+        if (refB >= 0) {
+            const double* rb = lds_s + m.rs_row[refB] * WAVE + lane;
+            dl[0] = ra[0] - rb[0]; dl[1] = ra[WAVE] - rb[WAVE]; dl[2] = ra[2 * WAVE] - rb[2 * WAVE];
+        } else {
+            const double* wc = m.ws_center + 3 * (~refB);
+            dl[0] = ra[0] - wc[0]; dl[1] = ra[WAVE] - wc[1]; dl[2] = ra[2 * WAVE] - wc[2];
+        }
+        const bool cand = active && !hit && (dot3(dl, dl) < rs * rs);
+        if (p < m.n_plane_pairs + m.n_closed_pairs) {
+            if (cand) {                               // point / segment cores: decide here
+                Core A, Bc;
+                load_core_any(m, lds_s, m.vp_canon[2 * p], lane, A);
+                load_core_any(m, lds_s, m.vp_canon[2 * p + 1], lane, Bc);
+                if (cores_collide_exact(A, Bc, tc)) hit = true;
+            }
+        } else {
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
+            if (bal != 0ull) {
+                if (cand) {
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    queue[pos] = ((unsigned)p << 6) | (unsigned)lane;
+                }
+                qn += __builtin_popcountll(bal);
+                if (qn > QUEUE_CAP - WAVE) {
+                    if (hit) lds_hit[lane] = 1u;
+                    drain_queue(m, lds_s, queue, qn, lds_hit, lane, thr);
+                    __syncthreads();
+                    qn = 0;
+                    hit = hit || (lds_hit[lane] != 0u);
+                }
+            }
+        }
+    }
+    if (hit) lds_hit[lane] = 1u;
+    drain_queue(m, lds_s, queue, qn, lds_hit, lane, thr);
+    __syncthreads();
+    return lds_hit[lane] != 0u;
 }
 
 __global__ __launch_bounds__(64) void k_validity(DevModel m, const double* __restrict__ q, int64_t B, double thr,
@@ -354,14 +476,280 @@ __global__ __launch_bounds__(64) void k_validity(DevModel m, const double* __res
     double* lds_q = lds;
     double* lds_s = lds_q + WAVE * m.n_q;
     double* lds_fr = lds_s + WAVE * m.shape_rows;
+    unsigned* lds_x = reinterpret_cast<unsigned*>(lds_fr + WAVE * 12 * m.frame_slots);
     // the raw slab is staged in the shape area (free until the sweep starts)
     stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
     const bool active = (base + lane) < B;
     sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
-    const bool hit = lane_collides(m, lds_s, lane, thr, active);
+    const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active);
     const uint64_t word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+}
+
+// ==== two-kernel validity for large batches ===========================================================
+// k_broad : one configuration per lane.  Sweeps the tree keeping ONLY the primitive centres (3 LDS rows per
+//           shape, so several waves fit a CU), runs the bounding-sphere test of every pair and appends the
+//           survivors (configuration, pair) to a GLOBAL queue: per wave one atomicAdd + one coalesced burst.
+//           The pair table of a wave lives in VGPRs (lane p holds pair p) and is broadcast with v_readlane,
+//           so the pair loop has no scalar-memory latency in it.
+// k_narrow: one queue item per lane, items are dense.  Replays the FK of the two primitives of its item
+//           from q, runs the exact predicate and ORs the configuration's bit into the mask.
+// Both kernels evaluate exactly the predicate of the fused kernel (and of the oracle), so the masks are
+// bit-identical; the fused kernel stays for small batches and for the edge kernel.
+constexpr int BQ_CAP = 1024;            // per-wave LDS staging of queue items before one global append
+
+NBK_DEV double readlane_f64(double v, int l) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+NBK_DEV void flush_items(unsigned* lds_queue, int qn, int64_t base_cfg, unsigned long long* q_count,
+                         unsigned long long* q_items, unsigned long long cap, int lane) {
+    __syncthreads();
+    unsigned long long off = 0;
+    if (lane == 0) off = atomicAdd(q_count, (unsigned long long)qn);
+    off = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(off >> 32)) << 32) |
+          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
+    for (int i = lane; i < qn; i += WAVE) {
+        const unsigned it = lds_queue[i];
+        const unsigned long long b = (unsigned long long)(base_cfg + (it & 63u));
+        if (off + i < cap) q_items[off + i] = (b << 20) | (unsigned long long)(it >> 6);
+    }
+    __syncthreads();
+}
+
+// LDS: raw q slab [64*n_q] | saved frames [12*slots][64] | centres [3*S][64] | queue [BQ_CAP] u32
+__global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restrict__ q, int64_t B, double thr,
+                                               uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+                                               unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
+                                               unsigned long long cap) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nq = m.n_q;
+    double* lds_raw = lds;
+    double* lds_fr = lds_raw + WAVE * nq;
+    double* lds_c = lds_fr + WAVE * 12 * m.frame_slots;
+    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_c + WAVE * 3 * m.n_rshapes);
+    // ---- stage q (coalesced), no transposed copy: lane reads lds_raw[lane*nq + j] -------------------------
+    {
+        const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+        const int total = (int)rows * nq;
+        const double* src = q + base * nq;
+        if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(lds_raw);
+            for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += WAVE) lds_raw[i] = src[i];
+            for (int i = total + lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.0;
+        }
+        __syncthreads();
+    }
+    const bool active = (base + lane) < B;
+    bool hit = false;
+    // ---- sweep: centres only ----------------------------------------------------------------------------------
+    {
+        Xf bpose;
+        xf_from12(m.base_pose, bpose);
+        Xf T = bpose;
+        for (int k = -1; k < m.n_joints; ++k) {
+            if (k >= 0) {
+                const int ld = m.joint_load[k];
+                Xf P;
+                if (ld == -2) P = T;
+                else if (ld == -1) P = bpose;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) P.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) P.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
+                }
+                const double qk = lds_raw[lane * nq + m.joint_qidx[k]];
+                joint_apply(m, k, P, qk, T);
+                const int sv = m.joint_save[k];
+                if (sv >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) lds_fr[(sv * 12 + e) * WAVE + lane] = T.R[e];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) lds_fr[(sv * 12 + 9 + e) * WAVE + lane] = T.t[e];
+                }
+            }
+            const int s0 = m.joint_shape_begin[k + 1], s1 = m.joint_shape_begin[k + 2];
+            for (int s = s0; s < s1; ++s) {
+                const double* loc = m.rs_local + 12 * s;
+                const double tl[3] = {loc[3], loc[7], loc[11]};
+                double c[3];
+                xf_mul_pos(T, tl, c);
+                double* rows = lds_c + (3 * s) * WAVE + lane;
+                rows[0] = c[0]; rows[WAVE] = c[1]; rows[2 * WAVE] = c[2];
+            }
+        }
+    }
+    // ---- broadphase ---------------------------------------------------------------------------------------------
+    int qn = 0;
+    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    for (int g0 = 0; g0 < P; g0 += WAVE) {
+        // lane j holds the constants of pair g0 + j
+        const int pj = g0 + lane;
+        int ia = 0, ib = 0, fl = 0;
+        double key = -1.0, wx = 0.0, wy = 0.0, wz = 0.0, px = 0.0, py = 0.0, pz = 0.0;
+        if (pj < P) {
+            ia = m.bp_tab[4 * pj]; ib = m.bp_tab[4 * pj + 1]; fl = m.bp_tab[4 * pj + 2];
+            const double* cst = m.vp_cst + 4 * pj;
+            if (pj < m.n_plane_pairs) {
+                // plane: key = (thr + mA) + rhoA is compared with the height above the plane
+                const double* wc = m.ws_core + 18 * (~ib);
+                wx = wc[9]; wy = wc[10]; wz = wc[11];             // unit normal
+                px = wc[0]; py = wc[1]; pz = wc[2];                // point on the plane
+                key = thr + cst[0];
+            } else {
+                const double tc = (thr + cst[0]) + cst[1];
+                const double rs = (tc + cst[2]) + cst[3];
+                key = rs > 0.0 ? rs * rs : -1.0;
+                if (ib < 0) { const double* wc = m.ws_center + 3 * (~ib); wx = wc[0]; wy = wc[1]; wz = wc[2]; }
+            }
+        }
+        const double rhoA = (pj < P) ? m.vp_cst[4 * pj + 2] : 0.0;
+        const int ng = (P - g0) < WAVE ? (P - g0) : WAVE;
+        for (int j = 0; j < ng; ++j) {
+            const int p = g0 + j;
+            const int sia = __builtin_amdgcn_readlane(ia, j);
+            const int sib = __builtin_amdgcn_readlane(ib, j);
+            const double skey = readlane_f64(key, j);
+            const double* ra = lds_c + sia * WAVE + lane;
+            bool cand;
+            if (p < m.n_plane_pairs) {
+                const double nx = readlane_f64(wx, j), ny = readlane_f64(wy, j), nz = readlane_f64(wz, j);
+                const double ox = readlane_f64(px, j), oy = readlane_f64(py, j), oz = readlane_f64(pz, j);
+                const double srho = readlane_f64(rhoA, j);
+                const double d[3] = {ra[0] - ox, ra[WAVE] - oy, ra[2 * WAVE] - oz};
+                const double n[3] = {nx, ny, nz};
+                const double hc = dot3(d, n);
+                cand = active && !hit && !((hc - srho) >= skey);
+            } else {
+                if (!(skey > 0.0)) continue;
+                double dl[3];
+                if (sib >= 0) {
+                    const double* rb = lds_c + sib * WAVE + lane;
+                    dl[0] = ra[0] - rb[0]; dl[1] = ra[WAVE] - rb[WAVE]; dl[2] = ra[2 * WAVE] - rb[2 * WAVE];
+                } else {
+                    dl[0] = ra[0] - readlane_f64(wx, j); dl[1] = ra[WAVE] - readlane_f64(wy, j); dl[2] = ra[2 * WAVE] - readlane_f64(wz, j);
+                }
+                cand = active && !hit && (dot3(dl, dl) < skey);
+                if (__builtin_amdgcn_readlane(fl, j) & 1) {
+                    // world box: midphase on this shape's centre (box constants are wave-uniform)
+                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+                        Core bx;
+                        load_wcore(m, ~sib, bx);
+                        const double* cst = m.vp_cst + 4 * p;
+                        const double tc = (thr + cst[0]) + cst[1];
+                        if (cand) {
+                            const double ca[3] = {ra[0], ra[WAVE], ra[2 * WAVE]};
+                            double cp[3], nn[3];
+                            const double dpb = point_solid(ca, bx, cp, nn);
+                            if (tc >= 0.0 && (dpb - cst[2]) >= tc) cand = false;
+                            else if (dpb < tc) { hit = true; cand = false; }
+                        }
+                    }
+                }
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
+            if (bal != 0ull) {
+                if (cand) {
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    lds_queue[pos] = ((unsigned)p << 6) | (unsigned)lane;
+                }
+                qn += __builtin_popcountll(bal);
+                if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            }
+        }
+    }
+    if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
+    // the mask starts from the hits certified here; k_narrow ORs the rest in
+    const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
+    if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
+    if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+}
+
+// core of shape `ref` (robot: from the replayed frame T; world: table).  Everything here is per lane.
+NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
+    if (ref >= 0) {
+        const double* loc = m.rs_local + 12 * ref;
+        const double* cc = m.rs_core + 6 * ref;
+        double Rl[9], tl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { Rl[3 * i] = loc[4 * i]; Rl[3 * i + 1] = loc[4 * i + 1]; Rl[3 * i + 2] = loc[4 * i + 2]; tl[i] = loc[4 * i + 3]; }
+        o.kind = m.rs_kind[ref];
+        o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4]; o.rho = cc[5];
+        xf_mul_pos(T, tl, o.c);
+        if (o.kind == K_SEG || o.kind == K_CYL) {
+            xf_mul_col(T, Rl, 2, o.ax[2]);
+        } else if (o.kind == K_BOX) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xf_mul_col(T, Rl, j, o.ax[j]);
+        }
+    } else {
+        load_wcore(m, ~ref, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_narrow(DevModel m, const double* __restrict__ q, double thr,
+                                                 const unsigned long long* __restrict__ q_items,
+                                                 const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                 uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    unsigned long long n = *q_count;
+    if (n > cap) n = cap;
+    if (m.dbg & 1) n = 0;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    // the trip count is made wave-uniform so that the joint loop below runs with scalar control flow
+    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+    for (unsigned long long i0 = first; i0 < n; i0 += stride) {
+        const unsigned long long i = i0 + (threadIdx.x & 63u);
+        const bool live = i < n;
+        unsigned long long item = 0;
+        if (live) item = q_items[i];
+        const long long b = (long long)(item >> 20);
+        const int p = (int)(item & 0xFFFFFull);
+        int ra = -1, rb = -1;
+        unsigned ma = 0u, mb = 0u;
+        if (live) {
+            ra = m.vp_canon[2 * p]; rb = m.vp_canon[2 * p + 1];
+            ma = ra >= 0 ? m.rs_mask[ra] : 0u;
+            mb = rb >= 0 ? m.rs_mask[rb] : 0u;
+        }
+        Xf TA, TB;
+        xf_from12(m.base_pose, TA);
+        TB = TA;
+        const double* qrow = q + b * m.n_q;
+        for (int k = 0; k < m.n_joints; ++k) {
+            const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
+            if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
+            if (in_a || in_b) {
+                const double qk = qrow[m.joint_qidx[k]];
+                Xf nxt;
+                joint_apply(m, k, in_a ? TA : TB, qk, nxt);     // common ancestors: TA == TB bit for bit
+                if (in_a) TA = nxt;
+                if (in_b) TB = nxt;
+            }
+        }
+        if (live) {
+            Core A, Bc;
+            build_core(m, ra, TA, A);
+            build_core(m, rb, TB, Bc);
+            const double* cst = m.vp_cst + 4 * p;
+            bool hit;
+            if (Bc.kind == K_PLANE) hit = plane_collides(A, Bc, thr, cst[2]);
+            else hit = cores_collide_exact(A, Bc, (thr + cst[0]) + cst[1]);
+            if (hit) {
+                if (mask_bits != nullptr) atomicOr(reinterpret_cast<unsigned long long*>(mask_bits) + (b >> 6), 1ull << (b & 63));
+                if (mask_bytes != nullptr) mask_bytes[b] = 1;
+            }
+        }
+    }
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses
@@ -418,6 +806,7 @@ __global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restri
     double* lds_q = lds;
     double* lds_s = lds_q + WAVE * nq;
     double* lds_fr = lds_s + WAVE * m.shape_rows;
+    unsigned* lds_x = reinterpret_cast<unsigned*>(lds_fr + WAVE * 12 * m.frame_slots);
     const double* s = starts + e * nq;
     const double* g = goals + e * nq;
     double d;
@@ -448,7 +837,7 @@ __global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restri
             lds_q[j * WAVE + lane] = a + bb;
         }
         sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
-        const bool hit = lane_collides(m, lds_s, lane, thr, active);
+        const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active);
         if (__builtin_amdgcn_ballot_w64(hit && active) != 0ull) ok = false;
     }
     if (lane == 0) { valid[e] = ok ? 1 : 0; if (n_samples) n_samples[e] = (int32_t)(n + 1); }
@@ -496,6 +885,17 @@ static void core_params(int type, const double* param, int& kind, double* cc) {
             break;
         case NBK_CYLINDER: kind = K_CYL; cc[4] = param[3]; cc[3] = param[0] - param[3]; cc[0] = param[1] - param[3]; break;
         default: kind = K_PLANE; break;
+    }
+}
+
+static double host_bound_radius(int kind, const double* cc) {
+    // must round exactly like the oracle's core_bound_radius
+    switch (kind) {
+        case K_POINT: return 0.0;
+        case K_SEG: return cc[0];
+        case K_CYL: return sqrt(fma(cc[3], cc[3], cc[0] * cc[0]));
+        case K_BOX: return sqrt(fma(cc[2], cc[2], fma(cc[1], cc[1], cc[0] * cc[0])));
+        default: return HUGE_VAL;
     }
 }
 
@@ -573,31 +973,33 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     begin[J + 1] = (int)order.size();
     std::vector<int> new_index(S);
     std::vector<int> rs_kind(S), rs_row(S);
-    std::vector<double> rs_local(12 * (size_t)S), rs_core(5 * (size_t)S);
+    std::vector<double> rs_local(12 * (size_t)S), rs_core(6 * (size_t)S);
     int rows = 0;
     for (int i = 0; i < S; ++i) {
         const int s = order[i];
         new_index[s] = i;
         int kind;
-        core_params(d->rshape_type[s], d->rshape_param + 4 * s, kind, &rs_core[5 * i]);
+        core_params(d->rshape_type[s], d->rshape_param + 4 * s, kind, &rs_core[6 * i]);
+        rs_core[6 * i + 5] = host_bound_radius(kind, &rs_core[6 * i]);
         rs_kind[i] = kind;
         rs_row[i] = rows;
         rows += host_core_rows(kind);
         memcpy(&rs_local[12 * i], d->rshape_local + 12 * s, 12 * sizeof(double));
     }
     std::vector<int> ws_kind(W);
-    std::vector<double> ws_core(17 * (size_t)W);
+    std::vector<double> ws_core(18 * (size_t)W);
     for (int w = 0; w < W; ++w) {
         double cc[5];
         int kind;
         core_params(d->wshape_type[w], d->wshape_param + 4 * w, kind, cc);
         ws_kind[w] = kind;
         const double* T = d->wshape_pose + 12 * w;
-        double* o = &ws_core[17 * w];
+        double* o = &ws_core[18 * w];
         o[0] = T[3]; o[1] = T[7]; o[2] = T[11];
         for (int j = 0; j < 3; ++j) { o[3 + 3 * j] = T[j]; o[4 + 3 * j] = T[4 + j]; o[5 + 3 * j] = T[8 + j]; }
         if (kind == K_PLANE) { o[9] = d->wshape_param[4 * w]; o[10] = d->wshape_param[4 * w + 1]; o[11] = d->wshape_param[4 * w + 2]; }
         o[12] = cc[0]; o[13] = cc[1]; o[14] = cc[2]; o[15] = cc[3]; o[16] = cc[4];
+        o[17] = host_bound_radius(kind, cc);
     }
     std::vector<int> pa(P), pb(P), pu(P);
     for (int p = 0; p < P; ++p) {
@@ -605,14 +1007,62 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         pb[p] = d->pair_b[p] < S ? new_index[d->pair_b[p]] : d->pair_b[p];
         pu[p] = p;
     }
-    // LDS budget: q rows + shape rows + saved frames, 512 B each; the raw q slab reuses the shape area
-    const size_t lds_bytes = (size_t)(d->n_q + (rows > d->n_q ? rows : d->n_q) + 12 * slots) * 64 * sizeof(double);
+    // validity tables: pairs stably sorted by class, refs (>= 0 robot shape in frame order, < 0 world ~ref)
+    std::vector<int> vcls(P), vorder(P);
+    auto kind_of = [&](int ref) { return ref >= 0 ? rs_kind[ref] : ws_kind[~ref]; };
+    auto core_of = [&](int ref) -> const double* { return ref >= 0 ? &rs_core[6 * ref] : &ws_core[18 * (~ref) + 12]; };
+    std::vector<int> refA(P), refB(P);
+    for (int p = 0; p < P; ++p) {
+        refA[p] = pa[p];
+        refB[p] = pb[p] < S ? pb[p] : ~(pb[p] - S);
+        const int ka = kind_of(refA[p]), kb = kind_of(refB[p]);
+        const bool a_ps = (ka == K_POINT || ka == K_SEG), b_ps = (kb == K_POINT || kb == K_SEG);
+        if (kb == K_PLANE) vcls[p] = 0;
+        else if ((a_ps && b_ps) || ka == K_POINT || kb == K_POINT) vcls[p] = 1;
+        else vcls[p] = 2;
+    }
+    int n_plane = 0, n_closed = 0, cur = 0;
+    for (int c = 0; c < 3; ++c)
+        for (int p = 0; p < P; ++p)
+            if (vcls[p] == c) { vorder[cur++] = p; if (c == 0) ++n_plane; if (c == 1) ++n_closed; }
+    std::vector<int> vp_tab(4 * (size_t)P), vp_canon(2 * (size_t)P);
+    std::vector<double> vp_cst(4 * (size_t)P), ws_center(3 * (size_t)W);
+    for (int i = 0; i < P; ++i) {
+        const int p = vorder[i];
+        const int ka = kind_of(refA[p]), kb = kind_of(refB[p]);
+        vp_tab[4 * i] = refA[p]; vp_tab[4 * i + 1] = refB[p]; vp_tab[4 * i + 2] = vcls[p]; vp_tab[4 * i + 3] = p;
+        const bool swap = ka > kb;
+        vp_canon[2 * i] = swap ? refB[p] : refA[p];
+        vp_canon[2 * i + 1] = swap ? refA[p] : refB[p];
+        const double* ca = core_of(refA[p]);
+        const double* cb = core_of(refB[p]);
+        vp_cst[4 * i] = ca[4]; vp_cst[4 * i + 1] = cb[4];
+        vp_cst[4 * i + 2] = host_bound_radius(ka, ca);
+        vp_cst[4 * i + 3] = host_bound_radius(kb, cb);
+    }
+    for (int w = 0; w < W; ++w) { ws_center[3 * w] = ws_core[18 * w]; ws_center[3 * w + 1] = ws_core[18 * w + 1]; ws_center[3 * w + 2] = ws_core[18 * w + 2]; }
+    std::vector<unsigned> frame_mask(J > 0 ? J : 1, 0u), rs_mask(S > 0 ? S : 1, 0u);
+    for (int k = 0; k < J; ++k) frame_mask[k] = (d->joint_parent[k] >= 0 ? frame_mask[d->joint_parent[k]] : 0u) | (1u << k);
+    for (int i = 0; i < S; ++i) { const int f = d->rshape_frame[order[i]]; rs_mask[i] = f >= 0 ? frame_mask[f] : 0u; }
+    std::vector<int> bp_tab(4 * (size_t)(P > 0 ? P : 1), 0);
+    for (int i = 0; i < P; ++i) {
+        const int p = vorder[i];
+        bp_tab[4 * i] = 3 * refA[p];
+        bp_tab[4 * i + 1] = refB[p] >= 0 ? 3 * refB[p] : refB[p];
+        bp_tab[4 * i + 2] = (refB[p] < 0 && ws_kind[~refB[p]] == K_BOX) ? 1 : 0;
+    }
+    if ((size_t)(d->n_q + 12 * slots + 3 * S) * 64 * sizeof(double) + BQ_CAP * 4 > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    if (P >= (1 << 20)) return NBK_ERR_UNSUPPORTED;
+    // LDS budget: q rows + shape rows + saved frames, 512 B each (+ queue and flags of the validity path);
+    // the raw q slab reuses the shape area
+    const size_t lds_bytes = (size_t)(d->n_q + (rows > d->n_q ? rows : d->n_q) + 12 * slots) * 64 * sizeof(double) + VALIDITY_LDS_EXTRA;
     if (lds_bytes > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    if (P >= (1 << 26)) return NBK_ERR_UNSUPPORTED;
 
     Blob B;
     nbk_model* M = new nbk_model();
     memset(&M->d, 0, sizeof(M->d));
-    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu; } o;
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt; } o;
     o.jt = B.add(d->joint_type, sizeof(int) * J);
     o.jq = B.add(d->joint_qidx, sizeof(int) * J);
     o.jl = B.add(load.data(), sizeof(int) * J);
@@ -626,12 +1076,18 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.rk = B.add(rs_kind.data(), sizeof(int) * S);
     o.rr = B.add(rs_row.data(), sizeof(int) * S);
     o.rl = B.add(rs_local.data(), sizeof(double) * 12 * S);
-    o.rc = B.add(rs_core.data(), sizeof(double) * 5 * S);
+    o.rc = B.add(rs_core.data(), sizeof(double) * 6 * S);
     o.wk = B.add(ws_kind.data(), sizeof(int) * W);
-    o.wc = B.add(ws_core.data(), sizeof(double) * 17 * W);
+    o.wc = B.add(ws_core.data(), sizeof(double) * 18 * W);
     o.pa = B.add(pa.data(), sizeof(int) * P);
     o.pb = B.add(pb.data(), sizeof(int) * P);
     o.pu = B.add(pu.data(), sizeof(int) * P);
+    o.vt = B.add(vp_tab.data(), sizeof(int) * 4 * P);
+    o.vc = B.add(vp_canon.data(), sizeof(int) * 2 * P);
+    o.vk = B.add(vp_cst.data(), sizeof(double) * 4 * P);
+    o.wz = B.add(ws_center.data(), sizeof(double) * 3 * W);
+    o.rm = B.add(rs_mask.data(), sizeof(unsigned) * S);
+    o.bt = B.add(bp_tab.data(), sizeof(int) * 4 * P);
     B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
 
     void* dev = nullptr;
@@ -663,7 +1119,16 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.pair_a = reinterpret_cast<const int*>(base + o.pa);
     m.pair_b = reinterpret_cast<const int*>(base + o.pb);
     m.pair_user = reinterpret_cast<const int*>(base + o.pu);
+    m.vp_tab = reinterpret_cast<const int*>(base + o.vt);
+    m.vp_canon = reinterpret_cast<const int*>(base + o.vc);
+    m.vp_cst = reinterpret_cast<const double*>(base + o.vk);
+    m.ws_center = reinterpret_cast<const double*>(base + o.wz);
+    m.n_plane_pairs = n_plane; m.n_closed_pairs = n_closed;
+    m.rs_mask = reinterpret_cast<const unsigned*>(base + o.rm);
+    m.bp_tab = reinterpret_cast<const int*>(base + o.bt);
+    { const char* ab = getenv("NBK_ABLATE"); m.dbg = ab ? atoi(ab) : 0; }
     M->blob = dev;
+    M->ws = nullptr; M->ws_bytes = 0;
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     (void)hipGetDevice(&M->device);
@@ -674,6 +1139,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
 void nbk_model_destroy(nbk_model* m) {
     if (m == nullptr) return;
     if (m->blob) (void)hipFree(m->blob);
+    if (m->ws) (void)hipFree(m->ws);
     delete m;
 }
 
@@ -724,17 +1190,76 @@ int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const
 }
 
 static inline size_t collide_lds(const nbk_model* m) {
-    return sizeof(double) * WAVE * ((size_t)m->d.n_q + (size_t)m->d.shape_rows + 12 * (size_t)m->d.frame_slots);
+    return sizeof(double) * WAVE * ((size_t)m->d.n_q + (size_t)m->d.shape_rows + 12 * (size_t)m->d.frame_slots) + VALIDITY_LDS_EXTRA;
+}
+
+// ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
+static const int64_t TWO_KERNEL_MIN_B = 8192;
+static const size_t WS_MAX_BYTES = size_t(1) << 30;
+
+static inline size_t broad_lds(const nbk_model* m) {
+    return sizeof(double) * WAVE * ((size_t)m->d.n_q + 12 * (size_t)m->d.frame_slots + 3 * (size_t)m->d.n_rshapes) + BQ_CAP * 4;
+}
+
+// configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
+static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
+    const int64_t P = m->n_pairs > 0 ? m->n_pairs : 1;
+    int64_t t = (int64_t)((WS_MAX_BYTES - 256) / (8 * (size_t)P));
+    t = (t / WAVE) * WAVE;
+    if (t < WAVE) t = WAVE;
+    return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
+}
+
+int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
+    if (m == nullptr || B < 0) return NBK_ERR_INVALID;
+    if (B < TWO_KERNEL_MIN_B || m->n_pairs == 0) return 0;
+    return 256 + 8 * tile_configs(m, B) * (int64_t)m->n_pairs;
+}
+
+int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+                              uint8_t* mask_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && q == nullptr) || (mask_bits == nullptr && mask_bytes == nullptr)) return NBK_ERR_INVALID;
+    if (B == 0) return NBK_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t need = nbk_validity_workspace_bytes(m, B);
+    if (need == 0 || workspace == nullptr || workspace_bytes < need) {
+        if (need != 0 && workspace != nullptr) return NBK_ERR_INVALID;       // a workspace was given but is too small
+        hipLaunchKernelGGL(k_validity, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), st, m->d, q, B, threshold, mask_bits, mask_bytes);
+        NBK_HIP(hipGetLastError());
+        return NBK_OK;
+    }
+    unsigned long long* count = static_cast<unsigned long long*>(workspace);
+    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + 256);
+    const int64_t tile = tile_configs(m, B);
+    const unsigned long long cap = (unsigned long long)tile * (unsigned long long)m->n_pairs;
+    for (int64_t b0 = 0; b0 < B; b0 += tile) {
+        const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
+        NBK_HIP(hipMemsetAsync(count, 0, 8, st));
+        // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
+        hipLaunchKernelGGL(k_broad, dim3(blocks_for(nb)), dim3(WAVE), broad_lds(m), st, m->d, q + b0 * m->n_q, nb, threshold,
+                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr, count, items, cap);
+        NBK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_narrow, dim3(2048), dim3(256), 0, st, m->d, q + b0 * m->n_q, threshold, items, count, cap,
+                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
+        NBK_HIP(hipGetLastError());
+    }
+    return NBK_OK;
 }
 
 int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                            uint8_t* mask_bytes, void* stream) {
-    if (m == nullptr || B < 0 || (B > 0 && q == nullptr) || (mask_bits == nullptr && mask_bytes == nullptr)) return NBK_ERR_INVALID;
-    if (B == 0) return NBK_OK;
-    hipLaunchKernelGGL(k_validity, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, threshold,
-                       mask_bits, mask_bytes);
-    NBK_HIP(hipGetLastError());
-    return NBK_OK;
+    if (m == nullptr) return NBK_ERR_INVALID;
+    const int64_t need = nbk_validity_workspace_bytes(m, B);
+    if (need <= 0) return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, nullptr, 0, stream);
+    nbk_model* mm = const_cast<nbk_model*>(m);
+    std::lock_guard<std::mutex> lock(mm->mu);          // one internal workspace: calls on one model serialise here
+    if (mm->ws_bytes < (size_t)need) {
+        if (mm->ws) { NBK_HIP(hipStreamSynchronize((hipStream_t)stream)); NBK_HIP(hipDeviceSynchronize()); (void)hipFree(mm->ws); mm->ws = nullptr; mm->ws_bytes = 0; }
+        hipError_t e = hipMalloc(&mm->ws, (size_t)need);
+        if (e != hipSuccess) { hip_fail(e, "hipMalloc(workspace)"); return NBK_ERR_ALLOC; }
+        mm->ws_bytes = (size_t)need;
+    }
+    return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, mm->ws, (int64_t)mm->ws_bytes, stream);
 }
 
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {

@@ -109,6 +109,7 @@ struct Core {
     double h[3];         // uniform: seg/cyl h[0] = half length; box half extents
     double rad;          // uniform: cylinder radius
     double margin;       // uniform
+    double rho;          // uniform: bounding radius of the core about c
 };
 
 NBK_DEV void core_support(const Core& s, const double* d, double* o) {
@@ -683,15 +684,31 @@ NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
     return dist;
 }
 
-// validity predicate of one pair: signed distance < thr, decided on the core distance against
-// tc = (thr + mA) + mB so that nothing is iterated or rooted once the answer is known.
-NBK_DEV bool cores_collide(const Core& A, const Core& Bc, double thr) {
-    if (Bc.kind == K_PLANE) {
-        double d[3];
-        sub3(A.c, Bc.c, d);
-        return (dot3(d, Bc.ax[2]) - core_halfwidth(A, Bc.ax[2])) < (thr + A.margin);
+// ---- validity predicate of one pair (spec = oracle cores_collide) ----------------------------------
+//   1. decided on the CORE distance against tc = (thr + mA) + mB  (user order of the pair);
+//   2. broadphase: |cA - cB|^2 >= ((tc + rhoA) + rhoB)^2, or a non-positive sum  => free;
+//   3. exact test with the cores in canonical order (kind ascending);
+//   planes (always second): t = thr + mA, hc = n.(cA - p0); hc - rhoA >= t => free, else hc - halfwidth < t.
+NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rhoA) {
+    double d[3];
+    sub3(A.c, Pl.c, d);
+    const double hc = dot3(d, Pl.ax[2]);
+    const double t = thr + A.margin;
+    if ((hc - rhoA) >= t) return false;            // broadphase: bounding sphere above the plane
+    return (hc - core_halfwidth(A, Pl.ax[2])) < t;
+}
+
+// steps 4-5 of the predicate (box midphase, exact test): A/Bc already in canonical order, neither is a plane
+NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
+    // midphase for box cores: the other core's centre against the exact box
+    if (A.kind == K_BOX || Bc.kind == K_BOX) {
+        double cp[3], nn[3];
+        double dpb, rho;
+        if (Bc.kind == K_BOX) { dpb = point_solid(A.c, Bc, cp, nn); rho = A.rho; }
+        else { dpb = point_solid(Bc.c, A, cp, nn); rho = Bc.rho; }
+        if (tc >= 0.0 && (dpb - rho) >= tc) return false;     // (tc < 0 compares a depth estimate: no cull)
+        if (dpb < tc) return true;
     }
-    const double tc = (thr + A.margin) + Bc.margin;
     const bool a_ps = (A.kind == K_POINT || A.kind == K_SEG), b_ps = (Bc.kind == K_POINT || Bc.kind == K_SEG);
     if (a_ps && b_ps) {
         double pa[3], pb[3], e[3];
@@ -700,7 +717,6 @@ NBK_DEV bool cores_collide(const Core& A, const Core& Bc, double thr) {
         return nbk_sqrt(dot3(e, e)) < tc;
     }
     if (A.kind == K_POINT) { double cp[3], nb[3]; return point_solid(A.c, Bc, cp, nb) < tc; }
-    if (Bc.kind == K_POINT) { double cp[3], na[3]; return point_solid(Bc.c, A, cp, na) < tc; }
     return gjk_collides(A, Bc, tc);
 }
 

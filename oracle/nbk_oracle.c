@@ -749,15 +749,61 @@ static double cores_distance(const core_t *A, const core_t *Bc, double *wit, int
     return dist;
 }
 
-/* predicate used by validity: is the signed distance below thr?  Decided on the CORE distance against
- * tc = (thr + mA) + mB so that no square root / iteration is spent once the answer is known. */
-static int cores_collide(const core_t *A, const core_t *Bc, double thr) {
-    if (Bc->kind == K_PLANE) {
-        double d[3];
-        sub3(A->c, Bc->c, d);
-        return (dot3(d, Bc->ax[2]) - core_halfwidth(A, Bc->ax[2])) < (thr + A->margin);
+/* bounding radius of a core about its centre (broadphase) */
+static double core_bound_radius(const core_t *s) {
+    switch (s->kind) {
+        case K_POINT: return 0.0;
+        case K_SEG: return s->h[0];
+        case K_CYL: return sqrt(FMA(s->rad, s->rad, s->h[0] * s->h[0]));
+        case K_BOX: return sqrt(FMA(s->h[2], s->h[2], FMA(s->h[1], s->h[1], s->h[0] * s->h[0])));
+        default: return INFINITY;
     }
-    const double tc = (thr + A->margin) + Bc->margin;
+}
+
+static __thread long long g_stat_items = 0, g_stat_survive = 0, g_stat_gjk = 0;   /* per thread: no sharing */
+
+/* predicate used by validity: is the signed distance below thr?
+ *   0. planes (always the second shape): t = thr + mA, height hc = n.(cA - p0); hc - rhoA >= t => free
+ *      (broadphase), else hc - halfwidth_A(n) < t;
+ *   1. decided on the CORE distance against tc = (thr + mA) + mB;
+ *   2. broadphase: bounding spheres -- |cA - cB|^2 >= ((tc + rhoA) + rhoB)^2 (or a non-positive sum) => free;
+ *   3. the two cores are taken in canonical order (kind ascending: point < segment < box < cylinder), so that
+ *      a device can evaluate all pairs of one kind class with one specialised routine;
+ *   4. midphase when a box core is involved: signed distance dpb of the OTHER core's centre to the exact box;
+ *      dpb - rho_other >= tc (and tc >= 0) => free, dpb < tc => colliding (the centre is a point of that core);
+ *   5. exact test: closed form for point/segment cores and point-vs-solid, GJK predicate otherwise. */
+static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
+    if (B0->kind == K_PLANE) {
+        double d[3];
+        sub3(A0->c, B0->c, d);
+        const double hc = dot3(d, B0->ax[2]);
+        const double t = thr + A0->margin;
+        if ((hc - core_bound_radius(A0)) >= t) return 0;       /* broadphase: bounding sphere above the plane */
+        return (hc - core_halfwidth(A0, B0->ax[2])) < t;
+    }
+    const double tc = (thr + A0->margin) + B0->margin;
+    const double rs = (tc + core_bound_radius(A0)) + core_bound_radius(B0);
+    double dl[3];
+    sub3(A0->c, B0->c, dl);
+    g_stat_items++;
+    if (!(rs > 0.0)) return 0;
+    if (dot3(dl, dl) >= rs * rs) return 0;
+    g_stat_survive++;
+    const core_t *A = A0, *Bc = B0;
+    if (A0->kind > B0->kind) { A = B0; Bc = A0; }
+    /* midphase for box cores: the other core's CENTRE (a point of that core) against the exact box.
+     * centre farther than the bounding radius => free; centre closer than tc => colliding. */
+    {
+        const core_t *bx = NULL, *ot = NULL;
+        if (Bc->kind == K_BOX) { bx = Bc; ot = A; }
+        else if (A->kind == K_BOX) { bx = A; ot = Bc; }
+        if (bx) {
+            double cp[3], nn[3];
+            const double dpb = point_solid(ot->c, bx, cp, nn);
+            if (tc >= 0.0 && (dpb - core_bound_radius(ot)) >= tc) return 0;   /* (tc < 0 compares a depth ESTIMATE: no cull) */
+            if (dpb < tc) return 1;
+        }
+    }
     const int a_ps = (A->kind == K_POINT || A->kind == K_SEG), b_ps = (Bc->kind == K_POINT || Bc->kind == K_SEG);
     if (a_ps && b_ps) {
         double pa[3], pb[3], e[3];
@@ -766,8 +812,13 @@ static int cores_collide(const core_t *A, const core_t *Bc, double thr) {
         return sqrt(dot3(e, e)) < tc;
     }
     if (A->kind == K_POINT) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
-    if (Bc->kind == K_POINT) { double cp[3], na[3]; return point_solid(Bc->c, A, cp, na) < tc; }
+    g_stat_gjk++;
     return gjk_collides(A, Bc, tc);
+}
+
+void orc_stats(long long *out, int reset) {
+    out[0] = g_stat_items; out[1] = g_stat_survive; out[2] = g_stat_gjk;
+    if (reset) { g_stat_items = g_stat_survive = g_stat_gjk = 0; }
 }
 
 double orc_shape_distance(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,

@@ -96,6 +96,10 @@ double orc_shape_distance(int32_t type_a, const double *pose_a, const double *pa
                           int32_t type_b, const double *pose_b, const double *param_b,
                           double *witness, int32_t *iters);
 
+/* broadphase statistics of the predicate since the last reset: items, survivors of the sphere test, GJK calls
+ * (single-threaded runs only; not synchronised) */
+void orc_stats(long long *out, int reset);
+
 /* the validity predicate of one pair: signed distance < threshold, decided with early outs */
 int orc_shape_collides(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
                        const double *pose_b, const double *param_b, double threshold);
