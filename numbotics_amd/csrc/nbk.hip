@@ -58,7 +58,9 @@ struct DevModel {
     const double* ws_center;      // [W][3]
     int n_plane_pairs, n_closed_pairs;   // class boundaries inside the sorted tables
     const unsigned* rs_mask;      // [S] joints on the path from the base to the shape's frame (bit k = joint k)
-    const int* bp_tab;            // [P][4] broadphase refs: LDS centre row of A, centre row of B or ~world index, flags (1 = B is a world box), pad
+    int bq_count[4];              // pairs per broadphase category
+    const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
+                                  //        index into the vp_* tables, category (0 plane, 1 robot-robot, 2 robot-world, 3 robot-world box)
     int dbg;                              // ablation switches for profiling builds (NBK_ABLATE env): 1 = no narrowphase, 2 = no pair loop
 };
 
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(64) void k_validity(DevModel m, const double* __res
 //           from q, runs the exact predicate and ORs the configuration's bit into the mask.
 // Both kernels evaluate exactly the predicate of the fused kernel (and of the oracle), so the masks are
 // bit-identical; the fused kernel stays for small batches and for the edge kernel.
-constexpr int BQ_CAP = 1024;            // per-wave LDS staging of queue items before one global append
+constexpr int BQ_CAP = 512;             // per-wave LDS staging of queue items before one global append
 
 NBK_DEV double readlane_f64(double v, int l) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -506,22 +508,54 @@ NBK_DEV double readlane_f64(double v, int l) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// The global queue is sharded into NSUB sub-queues (block b appends to sub-queue b % NSUB): one counter
+// saturates at ~90 appends/us (MI355X_MICROARCH.md, row "dequeue"), which 15k waves would all hit.
+constexpr int NSUB = 256;
+constexpr int CNT_STRIDE = 16;          // one 128-byte line per counter
+
 NBK_DEV void flush_items(unsigned* lds_queue, int qn, int64_t base_cfg, unsigned long long* q_count,
-                         unsigned long long* q_items, unsigned long long cap, int lane) {
+                         unsigned long long* q_items, unsigned long long cap_sub, int lane) {
     __syncthreads();
+    const unsigned sub = blockIdx.x % NSUB;
     unsigned long long off = 0;
-    if (lane == 0) off = atomicAdd(q_count, (unsigned long long)qn);
+    if (lane == 0) off = atomicAdd(q_count + sub * CNT_STRIDE, (unsigned long long)qn);
     off = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(off >> 32)) << 32) |
           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
+    unsigned long long* dst = q_items + (unsigned long long)sub * cap_sub;
     for (int i = lane; i < qn; i += WAVE) {
         const unsigned it = lds_queue[i];
         const unsigned long long b = (unsigned long long)(base_cfg + (it & 63u));
-        if (off + i < cap) q_items[off + i] = (b << 20) | (unsigned long long)(it >> 6);
+        if (off + i < cap_sub) dst[off + i] = (b << 20) | (unsigned long long)(it >> 6);
     }
     __syncthreads();
 }
 
-// LDS: raw q slab [64*n_q] | saved frames [12*slots][64] | centres [3*S][64] | queue [BQ_CAP] u32
+// LDS: raw q slab [64*n_q] | saved frames [12*slots][64] | centres [3*S][64] | pair constants [P][4] |
+//      world cores [W][18] | queue [BQ_CAP] u32.
+// Lane = configuration throughout.  Everything a pair needs that does not depend on the configuration
+// (rows, squared bounding radii for THIS threshold, box constants) is put into LDS once per wave and read
+// back with wave-uniform addresses (broadcast reads), so the pair loop touches no scalar or vector memory
+// and is a straight line per category.  Survivors are collected as one bit per (lane, pair) and turned into
+// queue items 64 pairs at a time.
+NBK_DEV void enqueue_bits(unsigned long long bits, int jbase, const double* lds_pc, unsigned* lds_queue, int& qn, int lane,
+                          int64_t base, unsigned long long* q_count, unsigned long long* q_items, unsigned long long cap) {
+    while (true) {
+        const bool has = bits != 0ull;
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+        if (bal == 0ull) break;
+        if (has) {
+            const int bit = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            const unsigned long long e0 = __builtin_bit_cast(unsigned long long, lds_pc[4 * (jbase + bit)]);
+            const unsigned p = (unsigned)(e0 >> 32) & 0xFFFFFu;
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            lds_queue[pos] = (p << 6) | (unsigned)lane;
+        }
+        qn += __builtin_popcountll(bal);
+        if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restrict__ q, int64_t B, double thr,
                                                uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                                                unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
@@ -530,16 +564,19 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nq = m.n_q;
+    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
     double* lds_raw = lds;
     double* lds_fr = lds_raw + WAVE * nq;
     double* lds_c = lds_fr + WAVE * 12 * m.frame_slots;
-    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_c + WAVE * 3 * m.n_rshapes);
+    double* lds_pc = lds_c + WAVE * 3 * m.n_rshapes;
+    double* lds_w = lds_pc + 4 * m.n_pairs;
+    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_w + 18 * m.n_wshapes);
+    const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
     // ---- stage q (coalesced), no transposed copy: lane reads lds_raw[lane*nq + j] -------------------------
     {
-        const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
-        const int total = (int)rows * nq;
+        const int total = rows_i * nq;
         const double* src = q + base * nq;
-        if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+        if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
             const double2* s2 = reinterpret_cast<const double2*>(src);
             double2* d2 = reinterpret_cast<double2*>(lds_raw);
             for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
@@ -547,9 +584,29 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
             for (int i = lane; i < total; i += WAVE) lds_raw[i] = src[i];
             for (int i = total + lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.0;
         }
-        __syncthreads();
     }
-    const bool active = (base + lane) < B;
+    // ---- per-wave constants: lane j prepares pair j ------------------------------------------------------------
+    for (int j = lane; j < P; j += WAVE) {
+        const int* t = m.bq_tab + 4 * j;
+        const int p = t[2], cat = t[3];
+        const double* cst = m.vp_cst + 4 * p;
+        const unsigned long long e0 = (unsigned long long)(unsigned)(t[0] & 0xFFFF) | ((unsigned long long)(unsigned)(t[1] & 0xFFFF) << 16) |
+                                      ((unsigned long long)(unsigned)p << 32) | ((unsigned long long)(unsigned)cat << 60);
+        double key, tc = 0.0;
+        if (cat == 0) key = thr + cst[0];
+        else {
+            tc = (thr + cst[0]) + cst[1];
+            const double rs = (tc + cst[2]) + cst[3];
+            key = rs > 0.0 ? rs * rs : -1.0;
+        }
+        lds_pc[4 * j] = __builtin_bit_cast(double, e0);
+        lds_pc[4 * j + 1] = key;
+        lds_pc[4 * j + 2] = tc;
+        lds_pc[4 * j + 3] = cst[2];
+    }
+    for (int i = lane; i < 18 * m.n_wshapes; i += WAVE) lds_w[i] = m.ws_core[i];
+    __syncthreads();
+    const bool active = lane < rows_i;
     bool hit = false;
     // ---- sweep: centres only ----------------------------------------------------------------------------------
     {
@@ -559,17 +616,17 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
         for (int k = -1; k < m.n_joints; ++k) {
             if (k >= 0) {
                 const int ld = m.joint_load[k];
-                Xf P;
-                if (ld == -2) P = T;
-                else if (ld == -1) P = bpose;
+                Xf Pf;
+                if (ld == -2) Pf = T;
+                else if (ld == -1) Pf = bpose;
                 else {
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) P.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
+                    for (int e = 0; e < 9; ++e) Pf.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) P.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
+                    for (int e = 0; e < 3; ++e) Pf.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
                 }
                 const double qk = lds_raw[lane * nq + m.joint_qidx[k]];
-                joint_apply(m, k, P, qk, T);
+                joint_apply(m, k, Pf, qk, T);
                 const int sv = m.joint_save[k];
                 if (sv >= 0) {
 #pragma unroll
@@ -589,84 +646,71 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
             }
         }
     }
-    // ---- broadphase ---------------------------------------------------------------------------------------------
+    // ---- broadphase: one bit per surviving (lane, pair) -------------------------------------------------------------
+    // Pairs are category-major; each category runs a branch-free body, unrolled so that the LDS reads of several
+    // pairs are in flight before the first use (the loop is latency-, not throughput-bound otherwise).
     int qn = 0;
-    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
-    for (int g0 = 0; g0 < P; g0 += WAVE) {
-        // lane j holds the constants of pair g0 + j
-        const int pj = g0 + lane;
-        int ia = 0, ib = 0, fl = 0;
-        double key = -1.0, wx = 0.0, wy = 0.0, wz = 0.0, px = 0.0, py = 0.0, pz = 0.0;
-        if (pj < P) {
-            ia = m.bp_tab[4 * pj]; ib = m.bp_tab[4 * pj + 1]; fl = m.bp_tab[4 * pj + 2];
-            const double* cst = m.vp_cst + 4 * pj;
-            if (pj < m.n_plane_pairs) {
-                // plane: key = (thr + mA) + rhoA is compared with the height above the plane
-                const double* wc = m.ws_core + 18 * (~ib);
-                wx = wc[9]; wy = wc[10]; wz = wc[11];             // unit normal
-                px = wc[0]; py = wc[1]; pz = wc[2];                // point on the plane
-                key = thr + cst[0];
+    int j0 = 0;
+    for (int cat = 0; cat < 4; ++cat) {
+        const int ncat = (m.dbg & 2) ? 0 : m.bq_count[cat];
+        for (int c0 = 0; c0 < ncat; c0 += WAVE) {
+            const int nn = (ncat - c0) < WAVE ? (ncat - c0) : WAVE;
+            const double* pc0 = lds_pc + 4 * (j0 + c0);
+            unsigned long long bits = 0ull;
+            if (cat == 1) {
+#pragma unroll 4
+                for (int u = 0; u < nn; ++u) {
+                    const unsigned long long e0 = __builtin_bit_cast(unsigned long long, pc0[4 * u]);
+                    const double key = pc0[4 * u + 1];
+                    const double* ra = lds_c + (int)(e0 & 0xFFFFull) * WAVE + lane;
+                    const double* rb = lds_c + (int)((e0 >> 16) & 0xFFFFull) * WAVE + lane;
+                    const double d[3] = {ra[0] - rb[0], ra[WAVE] - rb[WAVE], ra[2 * WAVE] - rb[2 * WAVE]};
+                    bits |= (dot3(d, d) < key) ? (1ull << u) : 0ull;
+                }
+            } else if (cat == 2) {
+#pragma unroll 4
+                for (int u = 0; u < nn; ++u) {
+                    const unsigned long long e0 = __builtin_bit_cast(unsigned long long, pc0[4 * u]);
+                    const double key = pc0[4 * u + 1];
+                    const double* ra = lds_c + (int)(e0 & 0xFFFFull) * WAVE + lane;
+                    const double* wc = lds_w + 18 * (int)((e0 >> 16) & 0xFFFFull);
+                    const double d[3] = {ra[0] - wc[0], ra[WAVE] - wc[1], ra[2 * WAVE] - wc[2]};
+                    bits |= (dot3(d, d) < key) ? (1ull << u) : 0ull;
+                }
+            } else if (cat == 3) {
+#pragma unroll 2
+                for (int u = 0; u < nn; ++u) {
+                    const unsigned long long e0 = __builtin_bit_cast(unsigned long long, pc0[4 * u]);
+                    const double key = pc0[4 * u + 1], tcb = pc0[4 * u + 2], rhoA = pc0[4 * u + 3];
+                    const double* ra = lds_c + (int)(e0 & 0xFFFFull) * WAVE + lane;
+                    const double* wc = lds_w + 18 * (int)((e0 >> 16) & 0xFFFFull);
+                    const double ca[3] = {ra[0], ra[WAVE], ra[2 * WAVE]};
+                    const double d[3] = {ca[0] - wc[0], ca[1] - wc[1], ca[2] - wc[2]};
+                    Core bx;
+                    bx.kind = K_BOX;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { bx.c[e] = wc[e]; bx.ax[0][e] = wc[3 + e]; bx.ax[1][e] = wc[6 + e]; bx.ax[2][e] = wc[9 + e]; bx.h[e] = wc[12 + e]; }
+                    bx.rad = 0.0; bx.margin = 0.0; bx.rho = 0.0;
+                    const int v = box_midphase(ca, rhoA, bx, tcb);
+                    const bool cand = (dot3(d, d) < key) && (v != 0);
+                    hit = hit || (cand && v == 1);
+                    bits |= cand ? (1ull << u) : 0ull;
+                }
             } else {
-                const double tc = (thr + cst[0]) + cst[1];
-                const double rs = (tc + cst[2]) + cst[3];
-                key = rs > 0.0 ? rs * rs : -1.0;
-                if (ib < 0) { const double* wc = m.ws_center + 3 * (~ib); wx = wc[0]; wy = wc[1]; wz = wc[2]; }
+                for (int u = 0; u < nn; ++u) {
+                    const unsigned long long e0 = __builtin_bit_cast(unsigned long long, pc0[4 * u]);
+                    const double key = pc0[4 * u + 1], rhoA = pc0[4 * u + 3];
+                    const double* ra = lds_c + (int)(e0 & 0xFFFFull) * WAVE + lane;
+                    const double* wc = lds_w + 18 * (int)((e0 >> 16) & 0xFFFFull);
+                    const double d[3] = {ra[0] - wc[0], ra[WAVE] - wc[1], ra[2 * WAVE] - wc[2]};
+                    const double n[3] = {wc[9], wc[10], wc[11]};
+                    bits |= !((dot3(d, n) - rhoA) >= key) ? (1ull << u) : 0ull;
+                }
             }
+            if (!active || hit || (m.dbg & 4)) bits = 0ull;
+            enqueue_bits(bits, j0 + c0, lds_pc, lds_queue, qn, lane, base, q_count, q_items, cap);
         }
-        const double rhoA = (pj < P) ? m.vp_cst[4 * pj + 2] : 0.0;
-        const int ng = (P - g0) < WAVE ? (P - g0) : WAVE;
-        for (int j = 0; j < ng; ++j) {
-            const int p = g0 + j;
-            const int sia = __builtin_amdgcn_readlane(ia, j);
-            const int sib = __builtin_amdgcn_readlane(ib, j);
-            const double skey = readlane_f64(key, j);
-            const double* ra = lds_c + sia * WAVE + lane;
-            bool cand;
-            if (p < m.n_plane_pairs) {
-                const double nx = readlane_f64(wx, j), ny = readlane_f64(wy, j), nz = readlane_f64(wz, j);
-                const double ox = readlane_f64(px, j), oy = readlane_f64(py, j), oz = readlane_f64(pz, j);
-                const double srho = readlane_f64(rhoA, j);
-                const double d[3] = {ra[0] - ox, ra[WAVE] - oy, ra[2 * WAVE] - oz};
-                const double n[3] = {nx, ny, nz};
-                const double hc = dot3(d, n);
-                cand = active && !hit && !((hc - srho) >= skey);
-            } else {
-                if (!(skey > 0.0)) continue;
-                double dl[3];
-                if (sib >= 0) {
-                    const double* rb = lds_c + sib * WAVE + lane;
-                    dl[0] = ra[0] - rb[0]; dl[1] = ra[WAVE] - rb[WAVE]; dl[2] = ra[2 * WAVE] - rb[2 * WAVE];
-                } else {
-                    dl[0] = ra[0] - readlane_f64(wx, j); dl[1] = ra[WAVE] - readlane_f64(wy, j); dl[2] = ra[2 * WAVE] - readlane_f64(wz, j);
-                }
-                cand = active && !hit && (dot3(dl, dl) < skey);
-                if (__builtin_amdgcn_readlane(fl, j) & 1) {
-                    // world box: midphase on this shape's centre (box constants are wave-uniform)
-                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
-                        Core bx;
-                        load_wcore(m, ~sib, bx);
-                        const double* cst = m.vp_cst + 4 * p;
-                        const double tc = (thr + cst[0]) + cst[1];
-                        if (cand) {
-                            const double ca[3] = {ra[0], ra[WAVE], ra[2 * WAVE]};
-                            double cp[3], nn[3];
-                            const double dpb = point_solid(ca, bx, cp, nn);
-                            if (tc >= 0.0 && (dpb - cst[2]) >= tc) cand = false;
-                            else if (dpb < tc) { hit = true; cand = false; }
-                        }
-                    }
-                }
-            }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
-            if (bal != 0ull) {
-                if (cand) {
-                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    lds_queue[pos] = ((unsigned)p << 6) | (unsigned)lane;
-                }
-                qn += __builtin_popcountll(bal);
-                if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
-            }
-        }
+        j0 += ncat;
     }
     if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
     // the mask starts from the hits certified here; k_narrow ORs the rest in
@@ -701,12 +745,17 @@ __global__ __launch_bounds__(256) void k_narrow(DevModel m, const double* __rest
                                                  const unsigned long long* __restrict__ q_items,
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
-    unsigned long long n = *q_count;
+    // block (sub, part): every NPART-th 256-item chunk of sub-queue `sub`
+    const unsigned sub = blockIdx.x % NSUB;
+    const unsigned part = blockIdx.x / NSUB;
+    const unsigned nparts = gridDim.x / NSUB;
+    unsigned long long n = q_count[sub * CNT_STRIDE];
     if (n > cap) n = cap;
     if (m.dbg & 1) n = 0;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    q_items += (unsigned long long)sub * cap;
+    const unsigned long long stride = (unsigned long long)nparts * blockDim.x;
     // the trip count is made wave-uniform so that the joint loop below runs with scalar control flow
-    const unsigned long long first = (unsigned long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63u);
+    const unsigned long long first = (unsigned long long)part * blockDim.x + (threadIdx.x & ~63u);
     for (unsigned long long i0 = first; i0 < n; i0 += stride) {
         const unsigned long long i = i0 + (threadIdx.x & 63u);
         const bool live = i < n;
@@ -1044,14 +1093,28 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     std::vector<unsigned> frame_mask(J > 0 ? J : 1, 0u), rs_mask(S > 0 ? S : 1, 0u);
     for (int k = 0; k < J; ++k) frame_mask[k] = (d->joint_parent[k] >= 0 ? frame_mask[d->joint_parent[k]] : 0u) | (1u << k);
     for (int i = 0; i < S; ++i) { const int f = d->rshape_frame[order[i]]; rs_mask[i] = f >= 0 ? frame_mask[f] : 0u; }
-    std::vector<int> bp_tab(4 * (size_t)(P > 0 ? P : 1), 0);
-    for (int i = 0; i < P; ++i) {
-        const int p = vorder[i];
-        bp_tab[4 * i] = 3 * refA[p];
-        bp_tab[4 * i + 1] = refB[p] >= 0 ? 3 * refB[p] : refB[p];
-        bp_tab[4 * i + 2] = (refB[p] < 0 && ws_kind[~refB[p]] == K_BOX) ? 1 : 0;
+    // broadphase order: category-major (0 plane, 1 robot-robot, 2 robot-world, 3 robot-world box), then by pair
+    std::vector<int> bq_tab(4 * (size_t)(P > 0 ? P : 1), 0);
+    {
+        int cur_b = 0;
+        for (int cat = 0; cat < 4; ++cat)
+            for (int i = 0; i < P; ++i) {
+                const int p = vorder[i];
+                int c;
+                if (refB[p] >= 0) c = 1;
+                else if (ws_kind[~refB[p]] == K_PLANE) c = 0;
+                else if (ws_kind[~refB[p]] == K_BOX) c = 3;
+                else c = 2;
+                if (c != cat) continue;
+                bq_tab[4 * cur_b] = 3 * refA[p];
+                bq_tab[4 * cur_b + 1] = refB[p] >= 0 ? 3 * refB[p] : ~refB[p];
+                bq_tab[4 * cur_b + 2] = i;
+                bq_tab[4 * cur_b + 3] = cat;
+                ++cur_b;
+            }
     }
-    if ((size_t)(d->n_q + 12 * slots + 3 * S) * 64 * sizeof(double) + BQ_CAP * 4 > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    if (3 * S >= 65536 || W >= 65536) return NBK_ERR_UNSUPPORTED;
+    if ((size_t)(d->n_q + 12 * slots + 3 * S) * 64 * sizeof(double) + (4 * (size_t)P + 18 * (size_t)W) * sizeof(double) + BQ_CAP * 4 > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     if (P >= (1 << 20)) return NBK_ERR_UNSUPPORTED;
     // LDS budget: q rows + shape rows + saved frames, 512 B each (+ queue and flags of the validity path);
     // the raw q slab reuses the shape area
@@ -1087,7 +1150,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.vk = B.add(vp_cst.data(), sizeof(double) * 4 * P);
     o.wz = B.add(ws_center.data(), sizeof(double) * 3 * W);
     o.rm = B.add(rs_mask.data(), sizeof(unsigned) * S);
-    o.bt = B.add(bp_tab.data(), sizeof(int) * 4 * P);
+    o.bt = B.add(bq_tab.data(), sizeof(int) * 4 * P);
     B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
 
     void* dev = nullptr;
@@ -1125,7 +1188,9 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.ws_center = reinterpret_cast<const double*>(base + o.wz);
     m.n_plane_pairs = n_plane; m.n_closed_pairs = n_closed;
     m.rs_mask = reinterpret_cast<const unsigned*>(base + o.rm);
-    m.bp_tab = reinterpret_cast<const int*>(base + o.bt);
+    m.bq_tab = reinterpret_cast<const int*>(base + o.bt);
+    for (int c = 0; c < 4; ++c) { m.bq_count[c] = 0; }
+    for (int i = 0; i < P; ++i) m.bq_count[bq_tab[4 * i + 3]]++;
     { const char* ab = getenv("NBK_ABLATE"); m.dbg = ab ? atoi(ab) : 0; }
     M->blob = dev;
     M->ws = nullptr; M->ws_bytes = 0;
@@ -1196,15 +1261,16 @@ static inline size_t collide_lds(const nbk_model* m) {
 // ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
 static const int64_t TWO_KERNEL_MIN_B = 8192;
 static const size_t WS_MAX_BYTES = size_t(1) << 30;
+static const size_t WS_HEADER = NSUB * CNT_STRIDE * 8;        // NSUB counters, one cache line each
 
 static inline size_t broad_lds(const nbk_model* m) {
-    return sizeof(double) * WAVE * ((size_t)m->d.n_q + 12 * (size_t)m->d.frame_slots + 3 * (size_t)m->d.n_rshapes) + BQ_CAP * 4;
+    return sizeof(double) * (WAVE * ((size_t)m->d.n_q + 12 * (size_t)m->d.frame_slots + 3 * (size_t)m->d.n_rshapes) + 4 * (size_t)m->d.n_pairs + 18 * (size_t)m->d.n_wshapes) + BQ_CAP * 4;
 }
 
 // configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
 static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
     const int64_t P = m->n_pairs > 0 ? m->n_pairs : 1;
-    int64_t t = (int64_t)((WS_MAX_BYTES - 256) / (8 * (size_t)P));
+    int64_t t = (int64_t)((WS_MAX_BYTES - WS_HEADER) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
     t = (t / WAVE) * WAVE;
     if (t < WAVE) t = WAVE;
     return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
@@ -1213,7 +1279,9 @@ static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
     if (m == nullptr || B < 0) return NBK_ERR_INVALID;
     if (B < TWO_KERNEL_MIN_B || m->n_pairs == 0) return 0;
-    return 256 + 8 * tile_configs(m, B) * (int64_t)m->n_pairs;
+    // NSUB sub-queues, each sized for the blocks that map to it (rounded up)
+    const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
+    return (int64_t)WS_HEADER + 8 * (int64_t)NSUB * ((nblk + NSUB - 1) / NSUB) * WAVE * (int64_t)m->n_pairs;
 }
 
 int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
@@ -1229,17 +1297,19 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
         return NBK_OK;
     }
     unsigned long long* count = static_cast<unsigned long long*>(workspace);
-    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + 256);
+    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + WS_HEADER);
     const int64_t tile = tile_configs(m, B);
-    const unsigned long long cap = (unsigned long long)tile * (unsigned long long)m->n_pairs;
     for (int64_t b0 = 0; b0 < B; b0 += tile) {
         const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
-        NBK_HIP(hipMemsetAsync(count, 0, 8, st));
+        const unsigned nblk = blocks_for(nb);
+        // worst case per sub-queue: every pair of every configuration of the blocks that map to it
+        const unsigned long long cap_sub = (unsigned long long)((nblk + NSUB - 1) / NSUB) * WAVE * (unsigned long long)m->n_pairs;
+        NBK_HIP(hipMemsetAsync(count, 0, WS_HEADER, st));
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
-        hipLaunchKernelGGL(k_broad, dim3(blocks_for(nb)), dim3(WAVE), broad_lds(m), st, m->d, q + b0 * m->n_q, nb, threshold,
-                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr, count, items, cap);
+        hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, q + b0 * m->n_q, nb, threshold,
+                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_narrow, dim3(2048), dim3(256), 0, st, m->d, q + b0 * m->n_q, threshold, items, count, cap,
+        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 8), dim3(256), 0, st, m->d, q + b0 * m->n_q, threshold, items, count, cap_sub,
                            mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
         NBK_HIP(hipGetLastError());
     }

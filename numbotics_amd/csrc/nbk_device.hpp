@@ -689,6 +689,30 @@ NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
 //   2. broadphase: |cA - cB|^2 >= ((tc + rhoA) + rhoB)^2, or a non-positive sum  => free;
 //   3. exact test with the cores in canonical order (kind ascending);
 //   planes (always second): t = thr + mA, hc = n.(cA - p0); hc - rhoA >= t => free, else hc - halfwidth < t.
+// centre c (bounding radius rho) of the other core against the exact box bx.
+// returns 0 = free, 1 = colliding, -1 = undecided.  Mirrors step 4 of the oracle's cores_collide.
+NBK_DEV int box_midphase(const double* c, double rho, const Core& bx, double tc) {
+    double d[3], ax[3], ex[3];
+    bool inside = true;
+    sub3(c, bx.c, d);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ax[j] = __builtin_fabs(dot3(d, bx.ax[j]));
+        ex[j] = ax[j] - bx.h[j];
+        if (ex[j] > 0.0) inside = false; else ex[j] = 0.0;
+    }
+    const double d2 = NBK_FMA(ex[2], ex[2], NBK_FMA(ex[1], ex[1], ex[0] * ex[0]));
+    if (!inside) {
+        if (tc >= 0.0) { const double r = tc + rho; if (d2 >= r * r) return 0; }
+        if (tc > 0.0 && d2 < tc * tc) return 1;
+        return -1;
+    }
+    double g = bx.h[0] - ax[0];
+    if (bx.h[1] - ax[1] < g) g = bx.h[1] - ax[1];
+    if (bx.h[2] - ax[2] < g) g = bx.h[2] - ax[2];
+    return (-g < tc) ? 1 : -1;
+}
+
 NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rhoA) {
     double d[3];
     sub3(A.c, Pl.c, d);
@@ -700,14 +724,13 @@ NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rh
 
 // steps 4-5 of the predicate (box midphase, exact test): A/Bc already in canonical order, neither is a plane
 NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
-    // midphase for box cores: the other core's centre against the exact box
+    // midphase for box cores: the other core's centre against the exact box (no square roots)
     if (A.kind == K_BOX || Bc.kind == K_BOX) {
-        double cp[3], nn[3];
-        double dpb, rho;
-        if (Bc.kind == K_BOX) { dpb = point_solid(A.c, Bc, cp, nn); rho = A.rho; }
-        else { dpb = point_solid(Bc.c, A, cp, nn); rho = Bc.rho; }
-        if (tc >= 0.0 && (dpb - rho) >= tc) return false;     // (tc < 0 compares a depth estimate: no cull)
-        if (dpb < tc) return true;
+        const bool b_is_box = Bc.kind == K_BOX;
+        int verdict;
+        if (b_is_box) verdict = box_midphase(A.c, A.rho, Bc, tc);
+        else verdict = box_midphase(Bc.c, Bc.rho, A, tc);
+        if (verdict >= 0) return verdict != 0;
     }
     const bool a_ps = (A.kind == K_POINT || A.kind == K_SEG), b_ps = (Bc.kind == K_POINT || Bc.kind == K_SEG);
     if (a_ps && b_ps) {

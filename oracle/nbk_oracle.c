@@ -769,8 +769,9 @@ static __thread long long g_stat_items = 0, g_stat_survive = 0, g_stat_gjk = 0; 
  *   2. broadphase: bounding spheres -- |cA - cB|^2 >= ((tc + rhoA) + rhoB)^2 (or a non-positive sum) => free;
  *   3. the two cores are taken in canonical order (kind ascending: point < segment < box < cylinder), so that
  *      a device can evaluate all pairs of one kind class with one specialised routine;
- *   4. midphase when a box core is involved: signed distance dpb of the OTHER core's centre to the exact box;
- *      dpb - rho_other >= tc (and tc >= 0) => free, dpb < tc => colliding (the centre is a point of that core);
+ *   4. midphase when a box core is involved, on the OTHER core's centre c (a point of that core), without
+ *      square roots: d2 = squared distance of c to the box; outside: d2 >= (tc + rho_other)^2 (tc >= 0) => free,
+ *      d2 < tc^2 (tc > 0) => colliding; inside at depth g: -g < tc => colliding;
  *   5. exact test: closed form for point/segment cores and point-vs-solid, GJK predicate otherwise. */
 static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     if (B0->kind == K_PLANE) {
@@ -798,10 +799,25 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
         if (Bc->kind == K_BOX) { bx = Bc; ot = A; }
         else if (A->kind == K_BOX) { bx = A; ot = Bc; }
         if (bx) {
-            double cp[3], nn[3];
-            const double dpb = point_solid(ot->c, bx, cp, nn);
-            if (tc >= 0.0 && (dpb - core_bound_radius(ot)) >= tc) return 0;   /* (tc < 0 compares a depth ESTIMATE: no cull) */
-            if (dpb < tc) return 1;
+            /* square-root free: x = centre in box coordinates, ex = excess beyond the faces */
+            double d[3], ax[3], ex[3];
+            int inside = 1;
+            sub3(ot->c, bx->c, d);
+            for (int j = 0; j < 3; ++j) {
+                ax[j] = fabs(dot3(d, bx->ax[j]));
+                ex[j] = ax[j] - bx->h[j];
+                if (ex[j] > 0.0) inside = 0; else ex[j] = 0.0;
+            }
+            const double d2 = FMA(ex[2], ex[2], FMA(ex[1], ex[1], ex[0] * ex[0]));
+            if (!inside) {
+                if (tc >= 0.0) { const double r = tc + core_bound_radius(ot); if (d2 >= r * r) return 0; }
+                if (tc > 0.0 && d2 < tc * tc) return 1;
+            } else {
+                double g = bx->h[0] - ax[0];
+                if (bx->h[1] - ax[1] < g) g = bx->h[1] - ax[1];
+                if (bx->h[2] - ax[2] < g) g = bx->h[2] - ax[2];
+                if (-g < tc) return 1;
+            }
         }
     }
     const int a_ps = (A->kind == K_POINT || A->kind == K_SEG), b_ps = (Bc->kind == K_POINT || Bc->kind == K_SEG);
