@@ -741,7 +741,7 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_narrow(DevModel m, const double* __restrict__ q, double thr,
+__global__ __launch_bounds__(256, 2) void k_narrow(DevModel m, const double* __restrict__ q, double thr,
                                                  const unsigned long long* __restrict__ q_items,
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
