@@ -139,24 +139,48 @@ NBK_DEV void joint_apply(const DevModel& m, int k, const Xf& parent, double qk, 
 // ---- FK of one frame -----------------------------------------------------------------------------
 struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; };
 
-// LDS: raw q slab (64*n_q) | q transposed (n_q*64) | output rows (64 * 17)
+// LDS: the raw q slab (64*n_q doubles) and the output rows (64 * 17 doubles) share one region: every q
+// value is in a register before the first pose element is written, so 8.7 KB per wave is all it takes and
+// 4+ waves per SIMD stay resident to cover the HBM latency (the kernel is bandwidth-bound: 184 B per pose).
 __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const double* __restrict__ q, int64_t B,
                                             const double* __restrict__ local_pose, double* __restrict__ T_out) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
-    double* lds_raw = lds;
-    double* lds_q = lds + WAVE * m.n_q;
-    double* lds_o = lds_q + WAVE * m.n_q;
-    stage_q(q, base, B, m.n_q, lds_raw, lds_q, lane);
+    const int nq = m.n_q;
+    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+    {
+        const int total = (int)rows * nq;
+        const double* src = q + base * nq;
+        if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(lds);
+            for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += WAVE) lds[i] = src[i];
+            for (int i = total + lane; i < WAVE * nq; i += WAVE) lds[i] = 0.0;
+        }
+        __syncthreads();
+    }
     Xf T;
     xf_from12(m.base_pose, T);
-    for (int i = 0; i < path.len; ++i) {
-        const int k = path.idx[i];
-        const double qk = lds_q[m.joint_qidx[k] * WAVE + lane];
-        Xf nxt;
-        joint_apply(m, k, T, qk, nxt);
-        T = nxt;
+    const double* myq = lds + lane * nq;
+    {
+        // two joints per trip (T -> U -> T): no register copies of the 3x4 frame across the loop back-edge
+        int i = 0;
+        for (; i + 1 < path.len; i += 2) {
+            const int k0 = path.idx[i], k1 = path.idx[i + 1];
+            const double q0 = myq[m.joint_qidx[k0]], q1 = myq[m.joint_qidx[k1]];
+            Xf U;
+            joint_apply(m, k0, T, q0, U);
+            joint_apply(m, k1, U, q1, T);
+        }
+        if (i < path.len) {
+            const int k = path.idx[i];
+            Xf U;
+            joint_apply(m, k, T, myq[m.joint_qidx[k]], U);
+            T = U;
+        }
     }
     Xf loc, E;
     xf_from12(path.local, loc);
@@ -169,8 +193,9 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
         xf_mul(E, P.R, P.t, E2);
         E = E2;
     }
+    __syncthreads();                   // all q reads are done: the region is reused for the transposed poses
     // transpose through LDS (row stride 17 doubles: conflict-free ds_write_b64)
-    double* row = lds_o + lane * 17;
+    double* row = lds + lane * 17;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         row[4 * i] = E.R[3 * i]; row[4 * i + 1] = E.R[3 * i + 1]; row[4 * i + 2] = E.R[3 * i + 2];
@@ -178,7 +203,6 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
     }
     row[12] = 0.0; row[13] = 0.0; row[14] = 0.0; row[15] = 1.0;
     __syncthreads();
-    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
     double2* dst = reinterpret_cast<double2*>(T_out + base * 16);
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
@@ -186,8 +210,8 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
         const int r = g >> 3, c2 = (g & 7) * 2;
         if (r < rows) {
             double2 v;
-            v.x = lds_o[r * 17 + c2];
-            v.y = lds_o[r * 17 + c2 + 1];
+            v.x = lds[r * 17 + c2];
+            v.y = lds[r * 17 + c2 + 1];
             dst[g] = v;
         }
     }
@@ -257,9 +281,26 @@ __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const
     const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
     double* dst = J_out + base * ncol;
     const int total = (int)rows * ncol;
-    for (int g = lane; g < total; g += WAVE) {
-        const int r = g / ncol, c = g - r * ncol;
-        dst[g] = lds_o[r * stride + c];
+    if ((ncol & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+        // 16-byte stores; (row, column) of the running element are advanced without divisions
+        int g = 2 * lane;
+        int r = g / ncol, c = g - r * ncol;
+        for (; g < total; g += 2 * WAVE) {
+            double2 v;
+            v.x = lds_o[r * stride + c];
+            v.y = lds_o[r * stride + c + 1];
+            *reinterpret_cast<double2*>(dst + g) = v;
+            c += 2 * WAVE;
+            while (c >= ncol) { c -= ncol; ++r; }
+        }
+    } else {
+        int g = lane;
+        int r = g / ncol, c = g - r * ncol;
+        for (; g < total; g += WAVE) {
+            dst[g] = lds_o[r * stride + c];
+            c += WAVE;
+            while (c >= ncol) { c -= ncol; ++r; }
+        }
     }
 }
 
@@ -1231,7 +1272,7 @@ int32_t nbk_fk_batch(const nbk_model* m, const double* q, int64_t B, const int32
     const int st = make_path(m, path, path_len, local, pa);
     if (st != NBK_OK) return st;
     if (B == 0) return NBK_OK;
-    const size_t lds = sizeof(double) * WAVE * (2 * (size_t)m->n_q + 17);
+    const size_t lds = sizeof(double) * WAVE * ((size_t)(m->n_q > 17 ? m->n_q : 17));
     hipLaunchKernelGGL(k_fk, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, local_pose, T_out);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
