@@ -118,9 +118,22 @@ def main():
     # ---- roofline of the dominant kernel (validity) ---------------------------------------------------
     alg_bytes = (hi - lo) * (8.0 * chain.dof) + n_words * 8.0
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_validity", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_config": 8.0 * chain.dof + 0.125,
+    traffic, fk_traffic, traffic_src = None, None, None
+    import glob
+    side = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if side:
+        # HBM bytes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction) of this same
+        # command at batch 1e6; scaled to this run's batch.  bench.py cannot host the profiler itself.
+        with open(side[-1]) as f:
+            tj = json.load(f)
+        scale = (hi - lo) / float(tj.get("batch", hi - lo))
+        traffic = tj["validity_step_hbm_bytes"] * scale
+        fk_traffic = tj["kernels"]["k_fk"]["hbm_bytes_corrected"] * scale
+        traffic_src = os.path.relpath(side[-1], ROOT)
+    roofline = {"bound": "hbm", "kernel": "k_broad + k_narrow (one nbk_validity_batch call)" if (hi - lo) >= 8192 else "k_validity",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_config": 8.0 * chain.dof + 0.125,
                 "note": "VALU-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md"}
 
     # ---- the HBM-bound kernel of the path: pose-writing FK of one frame -------------------------------
@@ -137,7 +150,7 @@ def main():
     fk_bytes = (hi - lo) * (8.0 * chain.dof + 128.0)
     fk_gbs = fk_bytes / (fk_ms * 1e-3) / 1e9
     fk_roofline = {"bound": "hbm", "kernel": "k_fk", "achieved": fk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": fk_gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": fk_ms,
+                   "frac": fk_gbs / HBM_PEAK_GBS, "traffic": fk_traffic, "kernel_ms": fk_ms, "algorithmic_bytes": fk_bytes,
                    "poses_per_s": (hi - lo) / (fk_ms * 1e-3), "algorithmic_bytes_per_config": 8.0 * chain.dof + 128.0}
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample ---------------------
@@ -151,7 +164,7 @@ def main():
         while True:
             orc.validity(q_host[:n_s], 0.0, nthreads=cores)
             reps_cpu += 1
-            if time.perf_counter() - t_start > 1.5 or reps_cpu >= 8:
+            if time.perf_counter() - t_start > 1.5 or reps_cpu >= 64:
                 break
         cpu_t = time.perf_counter() - t_start
         t1s = time.perf_counter()

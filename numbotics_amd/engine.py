@@ -147,20 +147,31 @@ class DeviceModel:
         return qs.out(out)
 
     # ---- collision -----------------------------------------------------------------------------
-    def validity(self, q, threshold=0.0, packed=False):
+    def validity_workspace_bytes(self, B: int) -> int:
+        return int(self._lib.nbk_validity_workspace_bytes(self._h, int(B)))
+
+    def validity(self, q, threshold=0.0, packed=False, workspace=None):
         """In-collision flags.  packed=False: (B,) bool; packed=True: (ceil(B/64),) int64 words
-        (bit b%64 of word b//64), the form the multi-GPU all-gather moves."""
+        (bit b%64 of word b//64), the form the multi-GPU all-gather moves.
+        `workspace`: optional torch uint8 CUDA tensor of at least validity_workspace_bytes(B) bytes
+        (caller-owned scratch: concurrent streams / graph capture); default = the descriptor's own."""
         torch = _require_gpu()
         qs = _Staged(q, self.n_q)
+        words = mask = None
         if packed:
-            words = torch.zeros(((qs.B + 63) // 64,), dtype=torch.int64, device=qs.device)
-            _lib.check(self._lib.nbk_validity_batch(self._h, qs.t.data_ptr(), qs.B, float(threshold),
-                                                    words.data_ptr(), None, self._stream()), "nbk_validity_batch")
-            return qs.out(words)
-        mask = torch.empty((qs.B,), dtype=torch.uint8, device=qs.device)
-        _lib.check(self._lib.nbk_validity_batch(self._h, qs.t.data_ptr(), qs.B, float(threshold), None,
-                                                mask.data_ptr(), self._stream()), "nbk_validity_batch")
-        return qs.out(mask.bool())
+            words = torch.empty(((qs.B + 63) // 64,), dtype=torch.int64, device=qs.device)   # every word is written
+        else:
+            mask = torch.empty((qs.B,), dtype=torch.uint8, device=qs.device)
+        wp = None if words is None else words.data_ptr()
+        mp = None if mask is None else mask.data_ptr()
+        if workspace is None:
+            _lib.check(self._lib.nbk_validity_batch(self._h, qs.t.data_ptr(), qs.B, float(threshold), wp, mp,
+                                                    self._stream()), "nbk_validity_batch")
+        else:
+            _lib.check(self._lib.nbk_validity_batch_ws(self._h, qs.t.data_ptr(), qs.B, float(threshold), wp, mp,
+                                                       workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                                       self._stream()), "nbk_validity_batch_ws")
+        return qs.out(words) if packed else qs.out(mask.bool())
 
     def closest(self, q):
         torch = _require_gpu()

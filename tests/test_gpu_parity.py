@@ -118,6 +118,31 @@ def test_validity_mask_bitwise(fresh_world, scene, torch_cuda):
         assert np.array_equal(arm.in_collision(q[:B]), orc.validity(q[:B]))
 
 
+def test_fused_and_two_kernel_paths_agree(fresh_world, torch_cuda):
+    """Small batches run the fused kernel, large ones broadphase + compacted narrowphase; same predicate, same
+    bits -- also with a caller-owned workspace and for every shape class of the zoo scene."""
+    torch = torch_cuda
+    arm, chain, obs = build_scene("c3")
+    _, dev = arm._scene_device()
+    orc = Oracle(arm.scene_model())
+    q = sample_q(chain, 40000, seed=12)
+    for thr in (0.0, 0.01, -0.002):
+        big = dev.validity(q, thr)                                        # two-kernel path (B >= 8192)
+        small = np.concatenate([dev.validity(q[i:i + 4096], thr) for i in range(0, 40000, 4096)])   # fused path
+        assert np.array_equal(big, small)
+        assert np.array_equal(big, orc.validity(q, thr, nthreads=8))
+    need = dev.validity_workspace_bytes(40000)
+    assert need > 0 and dev.validity_workspace_bytes(100) == 0
+    ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    assert np.array_equal(dev.validity(q, 0.0, workspace=ws), big if thr == 0.0 else dev.validity(q, 0.0))
+    words = dev.validity(q, 0.0, packed=True, workspace=ws)
+    from numbotics_amd.parallel import unpack_mask
+    assert np.array_equal(unpack_mask(words, 40000), dev.validity(q, 0.0))
+    from numbotics_amd._lib import NbkError
+    with pytest.raises(NbkError):
+        dev.validity(q, 0.0, workspace=ws[:1024])
+
+
 def ref_first(orc, q0):
     return orc.validity(q0.reshape(1, -1))[0]
 
