@@ -607,11 +607,13 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
     const int nq = m.n_q;
     const int P = (m.dbg & 2) ? 0 : m.n_pairs;
     double* lds_raw = lds;
-    double* lds_fr = lds_raw + WAVE * nq;
+    const int qrows = (WAVE * nq * 8 >= BQ_CAP * 4) ? nq : (BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+    double* lds_fr = lds_raw + WAVE * qrows;
     double* lds_c = lds_fr + WAVE * 12 * m.frame_slots;
     double* lds_pc = lds_c + WAVE * 3 * m.n_rshapes;
     double* lds_w = lds_pc + 4 * m.n_pairs;
-    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_w + 18 * m.n_wshapes);
+    // the queue reuses the q slab, which is dead once the sweep is over (host sizes the region for both)
+    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
     const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
     // ---- stage q (coalesced), no transposed copy: lane reads lds_raw[lane*nq + j] -------------------------
     {
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
             }
         }
     }
+    __syncthreads();            // the q slab is dead from here on: its LDS region becomes the item queue
     // ---- broadphase: one bit per surviving (lane, pair) -------------------------------------------------------------
     // Pairs are category-major; each category runs a branch-free body, unrolled so that the LDS reads of several
     // pairs are in flight before the first use (the loop is latency-, not throughput-bound otherwise).
@@ -1305,7 +1308,8 @@ static const size_t WS_MAX_BYTES = size_t(1) << 30;
 static const size_t WS_HEADER = NSUB * CNT_STRIDE * 8;        // NSUB counters, one cache line each
 
 static inline size_t broad_lds(const nbk_model* m) {
-    return sizeof(double) * (WAVE * ((size_t)m->d.n_q + 12 * (size_t)m->d.frame_slots + 3 * (size_t)m->d.n_rshapes) + 4 * (size_t)m->d.n_pairs + 18 * (size_t)m->d.n_wshapes) + BQ_CAP * 4;
+    const size_t qrows = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+    return sizeof(double) * (WAVE * (qrows + 12 * (size_t)m->d.frame_slots + 3 * (size_t)m->d.n_rshapes) + 4 * (size_t)m->d.n_pairs + 18 * (size_t)m->d.n_wshapes);
 }
 
 // configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
