@@ -218,32 +218,39 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
 }
 
 // ---- geometric Jacobian of one frame ---------------------------------------------------------------
-// LDS: raw q | q transposed | joint origins+axes [path_len*6][64] | output rows 64 * (6*n_q + 1)
+// Two sweeps instead of parking every joint frame in LDS: the first finds the end position, the second
+// recomputes the joint frames and writes the columns [w x (p_end - p_i); w] straight into the output rows.
+// LDS: raw q slab (64*n_q) | output rows 64 * stride  (25 KB for 7 DoF -> 6 waves per CU instead of 3).
 __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const double* __restrict__ q, int64_t B,
                                                   int mode, const double* __restrict__ pose, double* __restrict__ J_out) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nq = m.n_q;
-    double* lds_raw = lds;
-    double* lds_q = lds + WAVE * nq;
-    double* lds_f = lds_q + WAVE * nq;
-    double* lds_o = lds_f + WAVE * 6 * path.len;
-    stage_q(q, base, B, nq, lds_raw, lds_q, lane);
+    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+    double* lds_o = lds + WAVE * nq;
+    {
+        const int total = (int)rows * nq;
+        const double* src = q + base * nq;
+        if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(lds);
+            for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += WAVE) lds[i] = src[i];
+            for (int i = total + lane; i < WAVE * nq; i += WAVE) lds[i] = 0.0;
+        }
+        __syncthreads();
+    }
+    const double* myq = lds + lane * nq;
+    // ---- sweep 1: end position -------------------------------------------------------------------------
     Xf T;
     xf_from12(m.base_pose, T);
     for (int i = 0; i < path.len; ++i) {
         const int k = path.idx[i];
-        const double qk = lds_q[m.joint_qidx[k] * WAVE + lane];
         Xf nxt;
-        joint_apply(m, k, T, qk, nxt);
+        joint_apply(m, k, T, myq[m.joint_qidx[k]], nxt);
         T = nxt;
-        const double* a = m.joint_axis + 3 * k;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            lds_f[(6 * i + r) * WAVE + lane] = T.t[r];
-            lds_f[(6 * i + 3 + r) * WAVE + lane] = NBK_FMA(T.R[3 * r + 2], a[2], NBK_FMA(T.R[3 * r + 1], a[1], T.R[3 * r] * a[0]));
-        }
     }
     Xf loc, E;
     xf_from12(path.local, loc);
@@ -257,19 +264,25 @@ __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const
     } else if (mode == 2 && b < B) {
         pend[0] = pose[16 * b + 3]; pend[1] = pose[16 * b + 7]; pend[2] = pose[16 * b + 11];
     }
+    // ---- sweep 2: columns ------------------------------------------------------------------------------
     const int ncol = 6 * nq;
     const int stride = ncol + 1 + ((ncol + 1) & 1 ? 0 : 1);   // odd row stride: conflict-free
     double* row = lds_o + lane * stride;
     for (int c = 0; c < ncol; ++c) row[c] = 0.0;
+    xf_from12(m.base_pose, T);
     for (int i = 0; i < path.len; ++i) {
         const int k = path.idx[i];
         const int col = m.joint_qidx[k];
-        double p[3], w[3];
+        Xf nxt;
+        joint_apply(m, k, T, myq[col], nxt);
+        T = nxt;
+        const double* a = m.joint_axis + 3 * k;
+        double w[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { p[r] = lds_f[(6 * i + r) * WAVE + lane]; w[r] = lds_f[(6 * i + 3 + r) * WAVE + lane]; }
+        for (int r = 0; r < 3; ++r) w[r] = NBK_FMA(T.R[3 * r + 2], a[2], NBK_FMA(T.R[3 * r + 1], a[1], T.R[3 * r] * a[0]));
         if (m.joint_type[k] == NBK_REVOLUTE) {
             double d[3], v[3];
-            sub3(pend, p, d);
+            sub3(pend, T.t, d);
             cross3(w, d, v);
             row[0 * nq + col] = v[0]; row[1 * nq + col] = v[1]; row[2 * nq + col] = v[2];
             row[3 * nq + col] = w[0]; row[4 * nq + col] = w[1]; row[5 * nq + col] = w[2];
@@ -278,7 +291,6 @@ __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const
         }
     }
     __syncthreads();
-    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
     double* dst = J_out + base * ncol;
     const int total = (int)rows * ncol;
     if ((ncol & 1) == 0 && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
@@ -1291,7 +1303,7 @@ int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const
     if (B == 0) return NBK_OK;
     const int ncol = 6 * m->n_q;
     const int stride = ncol + 1 + ((ncol + 1) & 1 ? 0 : 1);
-    const size_t lds = sizeof(double) * WAVE * (2 * (size_t)m->n_q + 6 * (size_t)path_len + (size_t)stride);
+    const size_t lds = sizeof(double) * WAVE * ((size_t)m->n_q + (size_t)stride);
     if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_jacobian, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, mode, pose, J_out);
     NBK_HIP(hipGetLastError());
