@@ -66,6 +66,17 @@ struct DevModel {
 
 }  // namespace nbk
 
+namespace nbk {
+// optional q source of k_broad / k_narrow: configuration b is sample `map[b] & 0xffffffff` of edge `map[b] >> 32`,
+// q = (1-t)*start + t*goal (unfused, like SciPy's degree-1 de Boor), t = i*step for i < n, T_f for i == n
+struct EdgeSrc {
+    const double* starts;
+    const double* goals;
+    const double* plan;                  // [E][3] step, T_f, n (as double)
+    const unsigned long long* map;       // [total] or nullptr = plain q rows
+};
+}  // namespace nbk
+
 struct nbk_model {
     nbk::DevModel d;
     void* blob;
@@ -77,6 +88,8 @@ struct nbk_model {
     // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
     void* ws;
     size_t ws_bytes;
+    void* ews;                // scratch of the batched edge path
+    size_t ews_bytes;
     std::mutex mu;
 };
 
@@ -609,7 +622,14 @@ NBK_DEV void enqueue_bits(unsigned long long bits, int jbase, const double* lds_
     }
 }
 
-__global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restrict__ q, int64_t B, double thr,
+NBK_DEV double edge_t(const EdgeSrc& es, unsigned long long mp, unsigned& e_out) {
+    const unsigned e = (unsigned)(mp >> 32), i = (unsigned)mp;
+    const double* pl = es.plan + 3 * (size_t)e;
+    e_out = e;
+    return ((double)i < pl[2]) ? (double)i * pl[0] : pl[1];
+}
+
+__global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                                                unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
                                                unsigned long long cap) {
@@ -628,7 +648,19 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, const double* __restri
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
     const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
     // ---- stage q (coalesced), no transposed copy: lane reads lds_raw[lane*nq + j] -------------------------
-    {
+    if (es.map != nullptr) {
+        // edge mode: this lane's configuration is an interpolation sample
+        if (lane < rows_i) {
+            unsigned e;
+            const double t = edge_t(es, es.map[base + lane], e);
+            const double omt = 1.0 - t;
+            const double* sp = es.starts + (size_t)e * nq;
+            const double* gp = es.goals + (size_t)e * nq;
+            for (int j = 0; j < nq; ++j) { const double a = omt * sp[j]; const double bb = t * gp[j]; lds_raw[lane * nq + j] = a + bb; }
+        } else {
+            for (int j = 0; j < nq; ++j) lds_raw[lane * nq + j] = 0.0;
+        }
+    } else {
         const int total = rows_i * nq;
         const double* src = q + base * nq;
         if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
@@ -797,7 +829,7 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_narrow(DevModel m, const double* __restrict__ q, double thr,
+__global__ __launch_bounds__(256, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                  const unsigned long long* __restrict__ q_items,
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
@@ -830,11 +862,24 @@ __global__ __launch_bounds__(256, 2) void k_narrow(DevModel m, const double* __r
         xf_from12(m.base_pose, TA);
         TB = TA;
         const double* qrow = q + b * m.n_q;
+        const double* grow = qrow;
+        double et = 0.0, eomt = 0.0;
+        const bool edge = es.map != nullptr;
+        if (edge && live) {
+            unsigned e;
+            et = edge_t(es, es.map[b], e);
+            eomt = 1.0 - et;
+            qrow = es.starts + (size_t)e * m.n_q;
+            grow = es.goals + (size_t)e * m.n_q;
+        }
         for (int k = 0; k < m.n_joints; ++k) {
             const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
             if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
             if (in_a || in_b) {
-                const double qk = qrow[m.joint_qidx[k]];
+                const int qi = m.joint_qidx[k];
+                double qk;
+                if (edge) { const double a = eomt * qrow[qi]; const double bb = et * grow[qi]; qk = a + bb; }
+                else qk = qrow[qi];
                 Xf nxt;
                 joint_apply(m, k, in_a ? TA : TB, qk, nxt);     // common ancestors: TA == TB bit for bit
                 if (in_a) TA = nxt;
@@ -966,6 +1011,87 @@ __global__ void k_selftest(const double* __restrict__ a, const double* __restric
     so[i] = s; co[i] = c;
     sq[i] = nbk_sqrt(a[i]);
     dv[i] = a[i] / b[i];
+}
+
+// ==== batched DiscreteConnector over many edges: plan -> scan -> expand -> validity pipeline -> reduce ======
+// Every sample of every edge becomes one configuration of a flat batch that goes through k_broad / k_narrow
+// (q is generated on the fly from the edge's end points), so edges run at the batch-validity rate; the
+// one-wave-per-edge kernel above stays for a handful of edges, where its early exit and single launch win.
+__global__ void k_edge_plan(int nq, const double* __restrict__ starts, const double* __restrict__ goals,
+                            const double* __restrict__ dist, int64_t E, double resolution, double max_distance, int mode,
+                            double* __restrict__ plan, unsigned long long* __restrict__ cnt, double* __restrict__ end,
+                            int32_t* __restrict__ n_samples) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const double* s = starts + e * nq;
+    const double* g = goals + e * nq;
+    double d;
+    if (dist != nullptr) d = dist[e];
+    else {
+        double acc = 0.0;
+        for (int i = 0; i < nq; ++i) { const double df = g[i] - s[i]; acc = NBK_FMA(df, df, acc); }
+        d = nbk_sqrt(acc);
+    }
+    if (!(d > 1.1920928955078125e-07)) {
+        plan[3 * e] = 0.0; plan[3 * e + 1] = 0.0; plan[3 * e + 2] = 0.0;
+        cnt[e] = 0ull;
+        if (n_samples) n_samples[e] = 0;
+        if (end) for (int i = 0; i < nq; ++i) end[e * nq + i] = __builtin_nan("");
+        return;
+    }
+    const double Tf = (mode == NBK_STEER && d > max_distance) ? max_distance / d : 1.0;
+    const double step = resolution / d;
+    const double lenf = __builtin_ceil(Tf / step);
+    const long long n = lenf > 0.0 ? (long long)lenf : 0;
+    plan[3 * e] = step; plan[3 * e + 1] = Tf; plan[3 * e + 2] = (double)n;
+    cnt[e] = (unsigned long long)(n + 1);
+    if (n_samples) n_samples[e] = (int32_t)(n + 1);
+    if (end) {
+        if (mode == NBK_CONNECT) for (int i = 0; i < nq; ++i) end[e * nq + i] = g[i];
+        else {
+            const double omt = 1.0 - Tf;
+            for (int i = 0; i < nq; ++i) { const double a = omt * s[i]; const double bb = Tf * g[i]; end[e * nq + i] = a + bb; }
+        }
+    }
+}
+
+// exclusive prefix sum of cnt[0..E) into offs[0..E], one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restrict__ cnt, int64_t E, unsigned long long* __restrict__ offs) {
+    __shared__ unsigned long long part[1024];
+    const int t = threadIdx.x;
+    const int64_t chunk = (E + 1023) / 1024;
+    const int64_t lo = (int64_t)t * chunk, hi = (lo + chunk) < E ? (lo + chunk) : E;
+    unsigned long long acc = 0;
+    for (int64_t i = lo; i < hi; ++i) acc += cnt[i];
+    part[t] = acc;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+        offs[E] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[t];
+    for (int64_t i = lo; i < hi; ++i) { offs[i] = run; run += cnt[i]; }
+}
+
+__global__ __launch_bounds__(64) void k_edge_expand(const unsigned long long* __restrict__ offs, int64_t E, unsigned long long* __restrict__ map) {
+    const int64_t e = blockIdx.x;
+    const unsigned long long o = offs[e], n = offs[e + 1] - o;
+    for (unsigned long long i = threadIdx.x; i < n; i += WAVE) map[o + i] = ((unsigned long long)e << 32) | i;
+}
+
+__global__ __launch_bounds__(64) void k_edge_reduce(const unsigned long long* __restrict__ offs, int64_t E, const uint64_t* __restrict__ words,
+                                                     uint8_t* __restrict__ valid) {
+    const int64_t e = blockIdx.x;
+    const unsigned long long o = offs[e], n = offs[e + 1] - o;
+    bool hit = false;
+    for (unsigned long long i = threadIdx.x; i < n; i += WAVE) {
+        const unsigned long long b = o + i;
+        hit = hit || ((words[b >> 6] >> (b & 63)) & 1ull);
+    }
+    const unsigned long long any = __builtin_amdgcn_ballot_w64(hit);
+    if (threadIdx.x == 0) valid[e] = (n > 0 && any == 0ull) ? 1 : 0;
 }
 
 // ---- host side --------------------------------------------------------------------------------------
@@ -1250,6 +1376,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     { const char* ab = getenv("NBK_ABLATE"); m.dbg = ab ? atoi(ab) : 0; }
     M->blob = dev;
     M->ws = nullptr; M->ws_bytes = 0;
+    M->ews = nullptr; M->ews_bytes = 0;
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     (void)hipGetDevice(&M->device);
@@ -1261,6 +1388,7 @@ void nbk_model_destroy(nbk_model* m) {
     if (m == nullptr) return;
     if (m->blob) (void)hipFree(m->blob);
     if (m->ws) (void)hipFree(m->ws);
+    if (m->ews) (void)hipFree(m->ews);
     delete m;
 }
 
@@ -1333,12 +1461,42 @@ static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
     return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
 }
 
+// broadphase + narrowphase over B configurations (plain q rows, or the samples described by `es`), tiled so
+// that the worst-case queue fits the workspace
+static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+                                 uint8_t* mask_bytes, void* workspace, hipStream_t st) {
+    unsigned long long* count = static_cast<unsigned long long*>(workspace);
+    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + WS_HEADER);
+    const int64_t tile = tile_configs(m, B);
+    for (int64_t b0 = 0; b0 < B; b0 += tile) {
+        const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
+        const unsigned nblk = blocks_for(nb);
+        // worst case per sub-queue: every pair of every configuration of the blocks that map to it
+        const unsigned long long cap_sub = (unsigned long long)((nblk + NSUB - 1) / NSUB) * WAVE * (unsigned long long)m->n_pairs;
+        EdgeSrc es_tile = es;
+        if (es.map != nullptr) es_tile.map = es.map + b0;
+        NBK_HIP(hipMemsetAsync(count, 0, WS_HEADER, st));
+        // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
+        hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, nb, threshold,
+                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr, count, items, cap_sub);
+        NBK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 8), dim3(256), 0, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
+                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
+        NBK_HIP(hipGetLastError());
+    }
+    return NBK_OK;
+}
+
+static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
+    const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
+    return (int64_t)WS_HEADER + 8 * (int64_t)NSUB * ((nblk + NSUB - 1) / NSUB) * WAVE * (int64_t)(m->n_pairs > 0 ? m->n_pairs : 1);
+}
+
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
     if (m == nullptr || B < 0) return NBK_ERR_INVALID;
     if (B < TWO_KERNEL_MIN_B || m->n_pairs == 0) return 0;
     // NSUB sub-queues, each sized for the blocks that map to it (rounded up)
-    const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
-    return (int64_t)WS_HEADER + 8 * (int64_t)NSUB * ((nblk + NSUB - 1) / NSUB) * WAVE * (int64_t)m->n_pairs;
+    return two_kernel_workspace_bytes(m, B);
 }
 
 int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
@@ -1353,24 +1511,7 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
         NBK_HIP(hipGetLastError());
         return NBK_OK;
     }
-    unsigned long long* count = static_cast<unsigned long long*>(workspace);
-    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + WS_HEADER);
-    const int64_t tile = tile_configs(m, B);
-    for (int64_t b0 = 0; b0 < B; b0 += tile) {
-        const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
-        const unsigned nblk = blocks_for(nb);
-        // worst case per sub-queue: every pair of every configuration of the blocks that map to it
-        const unsigned long long cap_sub = (unsigned long long)((nblk + NSUB - 1) / NSUB) * WAVE * (unsigned long long)m->n_pairs;
-        NBK_HIP(hipMemsetAsync(count, 0, WS_HEADER, st));
-        // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
-        hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, q + b0 * m->n_q, nb, threshold,
-                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr, count, items, cap_sub);
-        NBK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 8), dim3(256), 0, st, m->d, q + b0 * m->n_q, threshold, items, count, cap_sub,
-                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
-        NBK_HIP(hipGetLastError());
-    }
-    return NBK_OK;
+    return launch_two_kernel(m, EdgeSrc{nullptr, nullptr, nullptr, nullptr}, q, B, threshold, mask_bits, mask_bytes, workspace, st);
 }
 
 int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
@@ -1411,6 +1552,8 @@ int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B,
     return NBK_OK;
 }
 
+static const int64_t EDGE_BATCH_MIN_E = 32;
+
 int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const double* goals, const double* dist, int64_t E,
                                 double resolution, double max_distance, int32_t mode, double threshold, uint8_t* valid,
                                 double* end, int32_t* n_samples, void* stream) {
@@ -1418,8 +1561,65 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
     if (!(resolution > 0.0) || !(max_distance > 0.0) || (mode != NBK_CONNECT && mode != NBK_STEER)) return NBK_ERR_INVALID;
     if (E == 0) return NBK_OK;
     if (E > 0x7fffffffLL) return NBK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_edges, dim3((unsigned)E), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, starts, goals, dist, E,
-                       resolution, max_distance, mode, threshold, valid, end, n_samples);
+    hipStream_t st = (hipStream_t)stream;
+    if (E < EDGE_BATCH_MIN_E || m->n_pairs == 0) {
+        // a handful of edges: one wave per edge, early exit, one launch
+        hipLaunchKernelGGL(k_edges, dim3((unsigned)E), dim3(WAVE), collide_lds(m), st, m->d, starts, goals, dist, E,
+                           resolution, max_distance, mode, threshold, valid, end, n_samples);
+        NBK_HIP(hipGetLastError());
+        return NBK_OK;
+    }
+    // many edges: flat batch of all samples (this path synchronises once to learn the sample count and keeps
+    // its scratch in the descriptor: calls on one descriptor serialise)
+    nbk_model* mm = const_cast<nbk_model*>(m);
+    std::lock_guard<std::mutex> lock(mm->mu);
+    auto grow = [&](void*& buf, size_t& have, size_t need) -> int32_t {
+        if (have >= need) return NBK_OK;
+        if (buf) { NBK_HIP(hipDeviceSynchronize()); (void)hipFree(buf); buf = nullptr; have = 0; }
+        hipError_t e = hipMalloc(&buf, need);
+        if (e != hipSuccess) { hip_fail(e, "hipMalloc(edge scratch)"); return NBK_ERR_ALLOC; }
+        have = need;
+        return NBK_OK;
+    };
+    const size_t head = ((size_t)E * 3 * 8 + (size_t)(E + 1) * 8 * 2 + 4095) & ~size_t(4095);   // plan | cnt | offs
+    int32_t rc = grow(mm->ews, mm->ews_bytes, head);
+    if (rc != NBK_OK) return rc;
+    double* plan = static_cast<double*>(mm->ews);
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(plan + 3 * E);
+    unsigned long long* offs = cnt + (E + 1);
+    hipLaunchKernelGGL(k_edge_plan, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, m->n_q, starts, goals, dist, E, resolution,
+                       max_distance, mode, plan, cnt, end, n_samples);
+    NBK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, E, offs);
+    NBK_HIP(hipGetLastError());
+    unsigned long long total = 0;
+    NBK_HIP(hipMemcpyAsync(&total, offs + E, 8, hipMemcpyDeviceToHost, st));
+    NBK_HIP(hipStreamSynchronize(st));
+    if (total == 0) { NBK_HIP(hipMemsetAsync(valid, 0, (size_t)E, st)); return NBK_OK; }
+    const size_t map_bytes = ((size_t)total * 8 + 4095) & ~size_t(4095);
+    const size_t words_bytes = (((size_t)total + 63) / 64 * 8 + 4095) & ~size_t(4095);
+    // the header must survive a reallocation: grow first, then recompute it if the buffer moved
+    if (mm->ews_bytes < head + map_bytes + words_bytes) {
+        rc = grow(mm->ews, mm->ews_bytes, head + map_bytes + words_bytes);
+        if (rc != NBK_OK) return rc;
+        plan = static_cast<double*>(mm->ews);
+        cnt = reinterpret_cast<unsigned long long*>(plan + 3 * E);
+        offs = cnt + (E + 1);
+        hipLaunchKernelGGL(k_edge_plan, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, m->n_q, starts, goals, dist, E, resolution,
+                           max_distance, mode, plan, cnt, end, n_samples);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, E, offs);
+        NBK_HIP(hipGetLastError());
+    }
+    unsigned long long* map = reinterpret_cast<unsigned long long*>(static_cast<char*>(mm->ews) + head);
+    uint64_t* words = reinterpret_cast<uint64_t*>(static_cast<char*>(mm->ews) + head + map_bytes);
+    rc = grow(mm->ws, mm->ws_bytes, (size_t)two_kernel_workspace_bytes(m, (int64_t)total));
+    if (rc != NBK_OK) return rc;
+    hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, map);
+    NBK_HIP(hipGetLastError());
+    EdgeSrc es{starts, goals, plan, map};
+    rc = launch_two_kernel(m, es, nullptr, (int64_t)total, threshold, words, nullptr, mm->ws, st);
+    if (rc != NBK_OK) return rc;
+    hipLaunchKernelGGL(k_edge_reduce, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, words, valid);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }
