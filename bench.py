@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1_000_000, help="configurations per GPU per step")
     ap.add_argument("--scene", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the control flow)")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -49,10 +51,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the device path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(0 if args.all_ranks_on_device0 else local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from numbotics_amd.physics import World
     from numbotics_amd.scenes import build_scene, sample_q

@@ -36,6 +36,12 @@ def allgather_mask_words(words, out=None):
         return words
     if out is None:
         out = torch.empty((world * words.numel(),), dtype=words.dtype, device=words.device)
+    if dist.get_backend() == "gloo" and words.is_cuda:
+        # rehearsal only (gloo has no CUDA all_gather_into_tensor): stage through the host
+        host = torch.empty((world * words.numel(),), dtype=words.dtype)
+        dist.all_gather_into_tensor(host, words.cpu().contiguous())
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, words.contiguous())
     return out
 

@@ -8,10 +8,11 @@ sm, dev = arm._scene_device()
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 rng = np.random.default_rng(3)
 lim = chain.joint_limits
-s = rng.uniform(lim[:,0], lim[:,1], (3*E, 7)); g = rng.uniform(lim[:,0], lim[:,1], (3*E, 7))
-keep = np.linalg.norm(g - s, axis=1) <= np.pi
-s, g = s[keep][:E], g[keep][:E]
-E = s.shape[0]
+# end points U(limits); the goal is pulled towards the start so that |dq| <= pi (max_distance of _test_rrt.py:98)
+s = rng.uniform(lim[:,0], lim[:,1], (E, 7)); g = rng.uniform(lim[:,0], lim[:,1], (E, 7))
+d = np.linalg.norm(g - s, axis=1)
+scale = np.minimum(1.0, rng.uniform(0.2, 1.0, E) * np.pi / d)
+g = s + (g - s) * scale[:, None]
 ts, tg = torch.from_numpy(s).cuda(), torch.from_numpy(g).cuda()
 for res in (0.01,):
     ok, end, ns = dev.edge_validity(ts, tg, res, np.pi)
