@@ -57,6 +57,7 @@ struct DevModel {
     const double* vp_cst;         // [P][4] mA, mB, rhoA, rhoB (user order)
     const double* ws_center;      // [W][3]
     int n_plane_pairs, n_closed_pairs;   // class boundaries inside the sorted tables
+    const int* rs_frame;          // [S] moving frame of each robot shape (frame order, non-decreasing)
     const unsigned* rs_mask;      // [S] joints on the path from the base to the shape's frame (bit k = joint k)
     int bq_count[4];              // pairs per broadphase category
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
@@ -807,6 +808,229 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
 }
 
+// ---- k_broad_reg<S>: the same broadphase with the centres of up to S robot shapes in REGISTERS ---------------
+// The shape and pair loops are unrolled at compile time (S is a template parameter; which (a, b) slots are real
+// pairs is run-time data), so cx[a] / cx[b] are plain registers: no LDS traffic in the pair tests and no LDS
+// budget for centres -- occupancy is set by VGPRs (~3 waves/SIMD) instead of by 17 KB of LDS per wave.
+// LDS: raw q slab (later the item queue) | saved frames | key / pair-index tables [S*S] and [W*S].
+template <int S>
+__global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
+                                                   uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+                                                   unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
+                                                   unsigned long long cap) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nq = m.n_q;
+    const int W = m.n_wshapes;
+    double* lds_raw = lds;
+    const int qrows = (WAVE * nq * 8 >= BQ_CAP * 4) ? nq : (BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+    double* lds_fr = lds_raw + WAVE * qrows;
+    double* lds_rkey = lds_fr + WAVE * 12 * m.frame_slots;      // [S*S] key of robot-robot slot (a,b), a < b; < 0 = no pair
+    double* lds_wkey = lds_rkey + S * S;                         // [W*S] key of (world w, robot a)
+    double* lds_wtc = lds_wkey + W * S;                          // [W*S] tc of (world box w, robot a)
+    int* lds_rp = reinterpret_cast<int*>(lds_wtc + W * S);       // [S*S] sorted pair index of the slot
+    int* lds_wp = lds_rp + S * S;                                // [W*S]
+    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
+    const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
+    // ---- stage q ------------------------------------------------------------------------------------------------------
+    if (es.map != nullptr) {
+        if (lane < rows_i) {
+            unsigned e;
+            const double t = edge_t(es, es.map[base + lane], e);
+            const double omt = 1.0 - t;
+            const double* sp = es.starts + (size_t)e * nq;
+            const double* gp = es.goals + (size_t)e * nq;
+            for (int j = 0; j < nq; ++j) { const double a = omt * sp[j]; const double bb = t * gp[j]; lds_raw[lane * nq + j] = a + bb; }
+        } else {
+            for (int j = 0; j < nq; ++j) lds_raw[lane * nq + j] = 0.0;
+        }
+    } else {
+        const int total = rows_i * nq;
+        const double* src = q + base * nq;
+        if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(lds_raw);
+            for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += WAVE) lds_raw[i] = src[i];
+            for (int i = total + lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.0;
+        }
+    }
+    // ---- per-wave tables: slot (a,b) -> key for THIS threshold and pair index ------------------------------------------------
+    for (int i = lane; i < S * S; i += WAVE) { lds_rkey[i] = -1.0; lds_rp[i] = -1; }
+    for (int i = lane; i < W * S; i += WAVE) { lds_wkey[i] = -1.0; lds_wtc[i] = 0.0; lds_wp[i] = -1; }
+    __syncthreads();
+    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    for (int j = lane; j < P; j += WAVE) {
+        const int* t = m.bq_tab + 4 * j;
+        const int a = t[0] / 3, p = t[2], cat = t[3];
+        const double* cst = m.vp_cst + 4 * p;
+        if (cat == 1) {
+            const int b = t[1] / 3;
+            const double tc = (thr + cst[0]) + cst[1];
+            const double rs = (tc + cst[2]) + cst[3];
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            lds_rkey[lo * S + hi] = rs > 0.0 ? rs * rs : -1.0;
+            lds_rp[lo * S + hi] = p;
+        } else {
+            const int w = t[1];
+            double key;
+            if (cat == 0) key = thr + cst[0];
+            else {
+                const double tc = (thr + cst[0]) + cst[1];
+                const double rs = (tc + cst[2]) + cst[3];
+                key = rs > 0.0 ? rs * rs : -1.0;
+                lds_wtc[w * S + a] = tc;
+            }
+            lds_wkey[w * S + a] = key;
+            lds_wp[w * S + a] = p;
+        }
+    }
+    __syncthreads();
+    const bool active = lane < rows_i;
+    bool hit = false;
+    // ---- sweep: centres into registers ---------------------------------------------------------------------------------------
+    double cx[S], cy[S], cz[S];
+    {
+        Xf bpose;
+        xf_from12(m.base_pose, bpose);
+        Xf T = bpose;
+        int kcur = -1;
+#pragma unroll
+        for (int sidx = 0; sidx < S; ++sidx) {
+            cx[sidx] = 0.0; cy[sidx] = 0.0; cz[sidx] = 0.0;
+            if (sidx < m.n_rshapes) {
+                const int f = m.rs_frame[sidx];
+                while (kcur < f) {
+                    ++kcur;
+                    const int k = kcur;
+                    const int ld = m.joint_load[k];
+                    Xf Pf;
+                    if (ld == -2) Pf = T;
+                    else if (ld == -1) Pf = bpose;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) Pf.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) Pf.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
+                    }
+                    const double qk = lds_raw[lane * nq + m.joint_qidx[k]];
+                    joint_apply(m, k, Pf, qk, T);
+                    const int sv = m.joint_save[k];
+                    if (sv >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) lds_fr[(sv * 12 + e) * WAVE + lane] = T.R[e];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) lds_fr[(sv * 12 + 9 + e) * WAVE + lane] = T.t[e];
+                    }
+                }
+                const double* loc = m.rs_local + 12 * sidx;
+                const double tl[3] = {loc[3], loc[7], loc[11]};
+                double c[3];
+                if (f < 0) xf_mul_pos(bpose, tl, c); else xf_mul_pos(T, tl, c);
+                cx[sidx] = c[0]; cy[sidx] = c[1]; cz[sidx] = c[2];
+            }
+        }
+    }
+    __syncthreads();            // the q slab is dead from here on: its LDS region becomes the item queue
+    int qn = 0;
+    // ---- robot-robot slots (static a < b) ----------------------------------------------------------------------------------------
+    if (m.bq_count[1] > 0) {
+#pragma unroll
+        for (int a = 0; a < S - 1; ++a) {
+            unsigned long long bits = 0ull;
+#pragma unroll
+            for (int b = a + 1; b < S; ++b) {
+                const double key = lds_rkey[a * S + b];
+                const double d[3] = {cx[a] - cx[b], cy[a] - cy[b], cz[a] - cz[b]};
+                bits |= (dot3(d, d) < key) ? (1ull << b) : 0ull;
+            }
+            if (!active || hit) bits = 0ull;
+            // enqueue this row's survivors
+            while (true) {
+                const bool has = bits != 0ull;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+                if (bal == 0ull) break;
+                if (has) {
+                    const int bit = __builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    const unsigned p = (unsigned)lds_rp[a * S + bit];
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    lds_queue[pos] = (p << 6) | (unsigned)lane;
+                }
+                qn += __builtin_popcountll(bal);
+                if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            }
+        }
+    }
+    // ---- world shapes (run-time loop) against the static robot shapes -------------------------------------------------------------
+    for (int w = 0; w < W; ++w) {
+        const double* wc = m.ws_core + 18 * w;
+        const int wk = m.ws_kind[w];
+        unsigned long long bits = 0ull;
+        if (wk == K_PLANE) {
+            const double n[3] = {wc[9], wc[10], wc[11]};
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (a < m.n_rshapes) {
+                    const double key = lds_wkey[w * S + a];
+                    const double rhoA = m.rs_core[6 * a + 5];
+                    const double d[3] = {cx[a] - wc[0], cy[a] - wc[1], cz[a] - wc[2]};
+                    const bool cand = (lds_wp[w * S + a] >= 0) && !((dot3(d, n) - rhoA) >= key);
+                    bits |= cand ? (1ull << a) : 0ull;
+                }
+            }
+        } else if (wk == K_BOX) {
+            Core bx;
+            bx.kind = K_BOX;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { bx.c[e] = wc[e]; bx.ax[0][e] = wc[3 + e]; bx.ax[1][e] = wc[6 + e]; bx.ax[2][e] = wc[9 + e]; bx.h[e] = wc[12 + e]; }
+            bx.rad = 0.0; bx.margin = 0.0; bx.rho = 0.0;
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (a < m.n_rshapes) {
+                    const double key = lds_wkey[w * S + a];
+                    const double ca[3] = {cx[a], cy[a], cz[a]};
+                    const double d[3] = {ca[0] - wc[0], ca[1] - wc[1], ca[2] - wc[2]};
+                    const int v = box_midphase(ca, m.rs_core[6 * a + 5], bx, lds_wtc[w * S + a]);
+                    const bool cand = (dot3(d, d) < key) && (v != 0);
+                    hit = hit || (cand && v == 1);
+                    bits |= cand ? (1ull << a) : 0ull;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (a < m.n_rshapes) {
+                    const double key = lds_wkey[w * S + a];
+                    const double d[3] = {cx[a] - wc[0], cy[a] - wc[1], cz[a] - wc[2]};
+                    bits |= (dot3(d, d) < key) ? (1ull << a) : 0ull;
+                }
+            }
+        }
+        if (!active || hit || (m.dbg & 4)) bits = 0ull;
+        while (true) {
+            const bool has = bits != 0ull;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+            if (bal == 0ull) break;
+            if (has) {
+                const int bit = __builtin_ctzll(bits);
+                bits &= bits - 1ull;
+                const unsigned p = (unsigned)lds_wp[w * S + bit];
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                lds_queue[pos] = (p << 6) | (unsigned)lane;
+            }
+            qn += __builtin_popcountll(bal);
+            if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+        }
+    }
+    if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
+    const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
+    if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
+    if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+}
+
 // core of shape `ref` (robot: from the replayed frame T; world: table).  Everything here is per lane.
 NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
     if (ref >= 0) {
@@ -1307,7 +1531,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     Blob B;
     nbk_model* M = new nbk_model();
     memset(&M->d, 0, sizeof(M->d));
-    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt; } o;
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf; } o;
     o.jt = B.add(d->joint_type, sizeof(int) * J);
     o.jq = B.add(d->joint_qidx, sizeof(int) * J);
     o.jl = B.add(load.data(), sizeof(int) * J);
@@ -1332,6 +1556,9 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.vk = B.add(vp_cst.data(), sizeof(double) * 4 * P);
     o.wz = B.add(ws_center.data(), sizeof(double) * 3 * W);
     o.rm = B.add(rs_mask.data(), sizeof(unsigned) * S);
+    std::vector<int> rs_frame_v(S > 0 ? S : 1, -1);
+    for (int i = 0; i < S; ++i) rs_frame_v[i] = d->rshape_frame[order[i]];
+    o.rf = B.add(rs_frame_v.data(), sizeof(int) * S);
     o.bt = B.add(bq_tab.data(), sizeof(int) * 4 * P);
     B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
 
@@ -1370,6 +1597,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.ws_center = reinterpret_cast<const double*>(base + o.wz);
     m.n_plane_pairs = n_plane; m.n_closed_pairs = n_closed;
     m.rs_mask = reinterpret_cast<const unsigned*>(base + o.rm);
+    m.rs_frame = reinterpret_cast<const int*>(base + o.rf);
     m.bq_tab = reinterpret_cast<const int*>(base + o.bt);
     for (int c = 0; c < 4; ++c) { m.bq_count[c] = 0; }
     for (int i = 0; i < P; ++i) m.bq_count[bq_tab[4 * i + 3]]++;
@@ -1461,6 +1689,12 @@ static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
     return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
 }
 
+static inline size_t broad_reg_lds(const nbk_model* m, int S) {
+    const size_t qrows = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+    const size_t W = (size_t)m->d.n_wshapes;
+    return sizeof(double) * (WAVE * (qrows + 12 * (size_t)m->d.frame_slots) + (size_t)S * S + 2 * W * S) + sizeof(int) * ((size_t)S * S + W * S) + 16;
+}
+
 // broadphase + narrowphase over B configurations (plain q rows, or the samples described by `es`), tiled so
 // that the worst-case queue fits the workspace
 static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
@@ -1477,8 +1711,19 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         if (es.map != nullptr) es_tile.map = es.map + b0;
         NBK_HIP(hipMemsetAsync(count, 0, WS_HEADER, st));
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
-        hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, nb, threshold,
-                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr, count, items, cap_sub);
+        const double* qt = q ? q + b0 * m->n_q : nullptr;
+        uint64_t* mb = mask_bits ? mask_bits + b0 / 64 : nullptr;
+        uint8_t* my = mask_bytes ? mask_bytes + b0 : nullptr;
+        const int S = m->d.n_rshapes;
+        const bool use_reg = S <= 16 && !getenv("NBK_NO_REG_BROAD");
+        if (use_reg && S <= 8)
+            hipLaunchKernelGGL(k_broad_reg<8>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 8), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+        else if (use_reg && S <= 12)
+            hipLaunchKernelGGL(k_broad_reg<12>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 12), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+        else if (use_reg)
+            hipLaunchKernelGGL(k_broad_reg<16>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 16), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+        else
+            hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_narrow, dim3(NSUB * 8), dim3(256), 0, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
                            mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
