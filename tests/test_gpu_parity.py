@@ -196,10 +196,12 @@ def test_shape_zoo_distances(fresh_world, torch_cuda):
     sm = arm.scene_model()
     assert sm.n_wshapes == 7
     orc = Oracle(sm)
-    q = sample_q(chain, 2000, seed=5)
-    assert_bitwise(arm.pair_distances(q), orc.pair_distances(q), "zoo distances")
-    for thr in (0.0, 0.03):
-        assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr))
+    q = sample_q(chain, 12000, seed=5)
+    assert_bitwise(arm.pair_distances(q[:2000]), orc.pair_distances(q[:2000]), "zoo distances")
+    for thr in (0.0, 0.03, -0.004):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref)                    # broadphase + narrowphase kernels
+        assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])      # fused kernel
 
 
 @pytest.mark.parametrize("mode", ["connect", "steer"])
@@ -280,3 +282,80 @@ def test_full_size_properties(fresh_world, torch_cuda):
     # threshold monotonicity
     m_hi = arm.in_collision(tq, 0.05).cpu().numpy()
     assert (m_hi | ~m1).all() and m_hi.sum() > m1.sum()
+
+
+TREE_URDF = __import__("os").path.join(__import__("os").path.dirname(__file__), "models", "tree_gripper.urdf")
+
+
+def test_tree_robot_with_prismatic_joints(fresh_world, torch_cuda):
+    """Branching chain (saved frames), prismatic joints, non-z axes: FK / Jacobian / masks / distances / edges,
+    through the fused kernel, the LDS broadphase and the register broadphase."""
+    import os
+    from numbotics_amd.physics import GraphChain, Cube, Sphere, Plane, Capsule
+    from numbotics_amd.robots import Arm
+    chain = GraphChain.from_urdf(TREE_URDF)
+    arm = Arm(chain)
+    assert chain.dof == 5
+    obs = [Cube(0.0, 0.08, position=np.array([0.35, 0.0, 0.55])), Sphere(0.0, 0.05, position=np.array([0.2, 0.2, 0.4])),
+           Plane(0.0, np.array([0.0, 0.0, 1.0]), position=np.array([0.0, 0.0, -0.01])),
+           Capsule(0.0, 0.03, 0.3, position=np.array([-0.2, 0.1, 0.6]))]
+    arm.remove_collision_pair("base", obs[2].name)          # the base sits on the ground
+    sm = arm.scene_model()
+    assert arm._kin.n_joints == 5 and sm.n_pairs > 20
+    orc_k, orc = Oracle(arm._kin), Oracle(sm)
+    q = sample_q(chain, 12000, seed=21)
+    for f in ("tip_a", "tip_b", "wrist_cam", "finger_b", "column"):
+        assert_bitwise(arm.forward_kinematics(q[:500], f), orc_k.fk(q[:500], f), f"tree fk {f}")
+        assert_bitwise(arm.jacobian(q[:500], f), orc_k.jacobian(q[:500], f), f"tree jac {f}")
+    # FK / Jacobian agree with finite differences (prismatic columns are pure translations)
+    J = arm.jacobian(q[:4], "tip_b")
+    h = 1e-6
+    for j in range(5):
+        qp, qm = q[:4].copy(), q[:4].copy()
+        qp[:, j] += h; qm[:, j] -= h
+        num = (arm.forward_kinematics(qp, "tip_b")[:, :3, 3] - arm.forward_kinematics(qm, "tip_b")[:, :3, 3]) / (2 * h)
+        assert np.abs(num - J[:, :3, j]).max() < 1e-8
+    for thr in (0.0, 0.01):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref)                        # register broadphase
+        assert np.array_equal(np.concatenate([arm.in_collision(q[i:i + 4000], thr) for i in range(0, 12000, 4000)]), ref)  # fused
+        os.environ["NBK_NO_REG_BROAD"] = "1"
+        try:
+            assert np.array_equal(arm.in_collision(q, thr), ref)                    # LDS broadphase
+        finally:
+            del os.environ["NBK_NO_REG_BROAD"]
+    assert 0.02 < orc.validity(q).mean() < 0.98
+    assert_bitwise(arm.pair_distances(q[:1000]), orc.pair_distances(q[:1000]), "tree distances")
+    _, dev = arm._scene_device()
+    s, g = q[:200], q[200:400]
+    ok, end, ns = dev.edge_validity(s, g, 0.02, 1.0, mode="steer")
+    okr, endr, nsr = orc.edge_validity(s, g, 0.02, 1.0, mode="steer")
+    assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
+    assert_bitwise(end, endr, "tree edge ends")
+
+
+def test_many_shapes_fall_back_to_lds_broadphase(fresh_world, torch_cuda, tmp_path):
+    """More than 16 robot primitives: k_broad (centres in LDS) instead of k_broad_reg."""
+    from numbotics_amd.physics import GraphChain, Cube
+    from numbotics_amd.robots import Arm
+    n = 9
+    parts = ['<?xml version="1.0"?><robot name="snake">', '<link name="l0"><collision><geometry><sphere radius="0.03"/></geometry></collision></link>']
+    for i in range(1, n + 1):
+        parts.append(f'<link name="l{i}"><collision><origin xyz="0 0 0.05"/><geometry><cylinder radius="0.02" length="0.1"/></geometry></collision>'
+                     f'<collision><origin xyz="0 0 0.1"/><geometry><sphere radius="0.025"/></geometry></collision></link>')
+        ax = ["1 0 0", "0 1 0", "0 0 1"][i % 3]
+        parts.append(f'<joint name="j{i}" type="revolute"><origin xyz="0 0 {0.0 if i == 1 else 0.1}"/><parent link="l{i-1}"/><child link="l{i}"/>'
+                     f'<axis xyz="{ax}"/><limit lower="-1.5" upper="1.5" effort="1" velocity="1"/></joint>')
+    parts.append('</robot>')
+    path = tmp_path / "snake.urdf"
+    path.write_text("\n".join(parts))
+    chain = GraphChain.from_urdf(str(path))
+    arm = Arm(chain)
+    cube = Cube(0.0, 0.1, position=np.array([0.25, 0.0, 0.4]))
+    sm = arm.scene_model()
+    assert sm.n_rshapes == 2 * n + 1 and sm.n_rshapes > 16
+    orc = Oracle(sm)
+    q = sample_q(chain, 10000, seed=5)
+    ref = orc.validity(q, 0.0, nthreads=8)
+    assert np.array_equal(arm.in_collision(q), ref) and 0.05 < ref.mean() < 0.95
+    assert np.array_equal(arm.in_collision(q[:3000]), ref[:3000])
