@@ -1,0 +1,19 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
+from numbotics_amd.physics import World
+from numbotics_amd.scenes import build_scene, sample_q
+World()
+arm, chain, obs = build_scene('c2')
+sm, dev = arm._scene_device()
+B = 200000
+q = torch.from_numpy(sample_q(chain, B, seed=1)).cuda()
+def t(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0,e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)/n
+print('closest ms %.3f for %d -> %.3e cfg/s'%((ms:=t(lambda: dev.closest(q))), B, B/ms*1e3))
+print('pair_distances ms %.3f -> %.3e cfg/s'%((ms:=t(lambda: dev.pair_distances(q))), B/ms*1e3))
+print('pair_distances+witness ms %.3f -> %.3e cfg/s'%((ms:=t(lambda: dev.pair_distances(q, witness=True))), B/ms*1e3))
