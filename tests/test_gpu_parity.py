@@ -359,3 +359,30 @@ def test_many_shapes_fall_back_to_lds_broadphase(fresh_world, torch_cuda, tmp_pa
     ref = orc.validity(q, 0.0, nthreads=8)
     assert np.array_equal(arm.in_collision(q), ref) and 0.05 < ref.mean() < 0.95
     assert np.array_equal(arm.in_collision(q[:3000]), ref[:3000])
+
+
+def test_iris_inner_steps(fresh_world, torch_cuda):
+    """The two collision-bound steps of IrisSolver.seperating_hyperplanes (safe_sets.py:124-134,186-201) on the
+    device, against the same loop run configuration by configuration on the oracle."""
+    from numbotics_amd.planning import collision_mask, counter_example_bisection
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    M = 10071                                  # upstream's first-iteration sample count (safe_sets.py:176-182)
+    pts = sample_q(chain, M, seed=31)
+    seed_q = np.zeros(7)
+    assert not arm.in_collision(seed_q, 1e-6)
+    mask = collision_mask(arm, pts, 1e-6)
+    assert np.array_equal(mask, orc.validity(pts, 1e-6, nthreads=8)) and mask.any()
+    col = pts[mask]
+    hi = counter_example_bisection(arm, seed_q, col, 15, 1e-6)
+    # reference loop, one sample at a time, on the oracle
+    for i in range(0, col.shape[0], max(1, col.shape[0] // 40)):
+        lo_i, hi_i = seed_q.copy(), col[i].copy()
+        for _ in range(15):
+            mid = (lo_i + hi_i) / 2.0
+            if orc.validity(mid[None], 1e-6)[0]:
+                hi_i = mid
+            else:
+                lo_i = mid
+        assert np.array_equal(hi_i, hi[i])
+    assert np.asarray(arm.in_collision(hi, 1e-6)).all()          # the returned ends are still colliding
