@@ -1053,11 +1053,77 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
     }
 }
 
-__global__ __launch_bounds__(256, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+// k_narrow: 128-thread workgroups take 128 queue items at a time.
+//   phase 1 (one item per lane, dense): FK replay of the item's two primitives, cores, planes / box midphase /
+//            closed forms; what is left for GJK is serialised into an LDS pool (36 doubles per item,
+//            component-major so that consecutive slots do not collide on banks);
+//   phase 2 (dynamic): every lane runs the GJK predicate ONE iteration per trip and, when its item is decided,
+//            takes the next pooled item -- iteration counts differ a lot between items (mean 2.2, max ~8), so a
+//            static item-to-lane assignment leaves two thirds of the lanes idle.
+constexpr int NARROW_T = 128;
+constexpr int POOL_E = 36;
+
+NBK_DEV void pool_put(double* pool, int slot, const Core& A, const Core& Bc, double tc, long long b) {
+    double* p = pool + slot;
+    const Core* cs[2] = {&A, &Bc};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const Core& o = *cs[c];
+        const int e0 = 17 * c;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            p[(e0 + e) * NARROW_T] = o.c[e];
+            p[(e0 + 3 + e) * NARROW_T] = o.ax[0][e];
+            p[(e0 + 6 + e) * NARROW_T] = o.ax[1][e];
+            p[(e0 + 9 + e) * NARROW_T] = o.ax[2][e];
+            p[(e0 + 12 + e) * NARROW_T] = o.h[e];
+        }
+        p[(e0 + 15) * NARROW_T] = o.rad;
+        p[(e0 + 16) * NARROW_T] = o.margin;
+    }
+    p[34 * NARROW_T] = tc;
+    const unsigned long long packed = ((unsigned long long)b << 8) | ((unsigned long long)(unsigned)A.kind << 4) | (unsigned long long)(unsigned)Bc.kind;
+    p[35 * NARROW_T] = __builtin_bit_cast(double, packed);
+}
+
+NBK_DEV void pool_get(const double* pool, int slot, Core& A, Core& Bc, double& tc, long long& b) {
+    const double* p = pool + slot;
+    const unsigned long long packed = __builtin_bit_cast(unsigned long long, p[35 * NARROW_T]);
+    b = (long long)(packed >> 8);
+    A.kind = (int)((packed >> 4) & 15ull);
+    Bc.kind = (int)(packed & 15ull);
+    Core* cs[2] = {&A, &Bc};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        Core& o = *cs[c];
+        const int e0 = 17 * c;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            o.c[e] = p[(e0 + e) * NARROW_T];
+            o.ax[0][e] = p[(e0 + 3 + e) * NARROW_T];
+            o.ax[1][e] = p[(e0 + 6 + e) * NARROW_T];
+            o.ax[2][e] = p[(e0 + 9 + e) * NARROW_T];
+            o.h[e] = p[(e0 + 12 + e) * NARROW_T];
+        }
+        o.rad = p[(e0 + 15) * NARROW_T];
+        o.margin = p[(e0 + 16) * NARROW_T];
+        o.rho = 0.0;
+    }
+    tc = p[34 * NARROW_T];
+}
+
+NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
+    if (mask_bits != nullptr) atomicOr(reinterpret_cast<unsigned long long*>(mask_bits) + (b >> 6), 1ull << (b & 63));
+    if (mask_bytes != nullptr) mask_bytes[b] = 1;
+}
+
+__global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                  const unsigned long long* __restrict__ q_items,
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
-    // block (sub, part): every NPART-th 256-item chunk of sub-queue `sub`
+    __shared__ double pool[POOL_E * NARROW_T];
+    __shared__ int pool_n, pool_next;
+    // block (sub, part): every nparts-th 128-item chunk of sub-queue `sub`
     const unsigned sub = blockIdx.x % NSUB;
     const unsigned part = blockIdx.x / NSUB;
     const unsigned nparts = gridDim.x / NSUB;
@@ -1065,64 +1131,118 @@ __global__ __launch_bounds__(256, 2) void k_narrow(DevModel m, EdgeSrc es, const
     if (n > cap) n = cap;
     if (m.dbg & 1) n = 0;
     q_items += (unsigned long long)sub * cap;
-    const unsigned long long stride = (unsigned long long)nparts * blockDim.x;
-    // the trip count is made wave-uniform so that the joint loop below runs with scalar control flow
-    const unsigned long long first = (unsigned long long)part * blockDim.x + (threadIdx.x & ~63u);
-    for (unsigned long long i0 = first; i0 < n; i0 += stride) {
-        const unsigned long long i = i0 + (threadIdx.x & 63u);
-        const bool live = i < n;
-        unsigned long long item = 0;
-        if (live) item = q_items[i];
-        const long long b = (long long)(item >> 20);
-        const int p = (int)(item & 0xFFFFFull);
-        int ra = -1, rb = -1;
-        unsigned ma = 0u, mb = 0u;
-        if (live) {
-            ra = m.vp_canon[2 * p]; rb = m.vp_canon[2 * p + 1];
-            ma = ra >= 0 ? m.rs_mask[ra] : 0u;
-            mb = rb >= 0 ? m.rs_mask[rb] : 0u;
-        }
-        Xf TA, TB;
-        xf_from12(m.base_pose, TA);
-        TB = TA;
-        const double* qrow = q + b * m.n_q;
-        const double* grow = qrow;
-        double et = 0.0, eomt = 0.0;
-        const bool edge = es.map != nullptr;
-        if (edge && live) {
-            unsigned e;
-            et = edge_t(es, es.map[b], e);
-            eomt = 1.0 - et;
-            qrow = es.starts + (size_t)e * m.n_q;
-            grow = es.goals + (size_t)e * m.n_q;
-        }
-        for (int k = 0; k < m.n_joints; ++k) {
-            const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
-            if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
-            if (in_a || in_b) {
-                const int qi = m.joint_qidx[k];
-                double qk;
-                if (edge) { const double a = eomt * qrow[qi]; const double bb = et * grow[qi]; qk = a + bb; }
-                else qk = qrow[qi];
-                Xf nxt;
-                joint_apply(m, k, in_a ? TA : TB, qk, nxt);     // common ancestors: TA == TB bit for bit
-                if (in_a) TA = nxt;
-                if (in_b) TB = nxt;
+    const int lane = threadIdx.x & 63;
+    for (unsigned long long i0 = (unsigned long long)part * NARROW_T; i0 < n; i0 += (unsigned long long)nparts * NARROW_T) {
+        if (threadIdx.x == 0) { pool_n = 0; pool_next = 0; }
+        __syncthreads();
+        // ---- phase 1 -----------------------------------------------------------------------------------------------
+        {
+            const unsigned long long i = i0 + threadIdx.x;
+            const bool live = i < n;
+            unsigned long long item = 0;
+            if (live) item = q_items[i];
+            const long long b = (long long)(item >> 20);
+            const int p = (int)(item & 0xFFFFFull);
+            int ra = -1, rb = -1;
+            unsigned ma = 0u, mb = 0u;
+            if (live) {
+                ra = m.vp_canon[2 * p]; rb = m.vp_canon[2 * p + 1];
+                ma = ra >= 0 ? m.rs_mask[ra] : 0u;
+                mb = rb >= 0 ? m.rs_mask[rb] : 0u;
             }
-        }
-        if (live) {
+            Xf TA, TB;
+            xf_from12(m.base_pose, TA);
+            TB = TA;
+            const double* qrow = q + b * m.n_q;
+            const double* grow = qrow;
+            double et = 0.0, eomt = 0.0;
+            const bool edge = es.map != nullptr;
+            if (edge && live) {
+                unsigned e;
+                et = edge_t(es, es.map[b], e);
+                eomt = 1.0 - et;
+                qrow = es.starts + (size_t)e * m.n_q;
+                grow = es.goals + (size_t)e * m.n_q;
+            }
+            for (int k = 0; k < m.n_joints; ++k) {
+                const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
+                if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
+                if (in_a || in_b) {
+                    const int qi = m.joint_qidx[k];
+                    double qk;
+                    if (edge) { const double a = eomt * qrow[qi]; const double bb = et * grow[qi]; qk = a + bb; }
+                    else qk = qrow[qi];
+                    Xf nxt;
+                    joint_apply(m, k, in_a ? TA : TB, qk, nxt);     // common ancestors: TA == TB bit for bit
+                    if (in_a) TA = nxt;
+                    if (in_b) TB = nxt;
+                }
+            }
+            bool pooled = false;
             Core A, Bc;
-            build_core(m, ra, TA, A);
-            build_core(m, rb, TB, Bc);
-            const double* cst = m.vp_cst + 4 * p;
-            bool hit;
-            if (Bc.kind == K_PLANE) hit = plane_collides(A, Bc, thr, cst[2]);
-            else hit = cores_collide_exact(A, Bc, (thr + cst[0]) + cst[1]);
-            if (hit) {
-                if (mask_bits != nullptr) atomicOr(reinterpret_cast<unsigned long long*>(mask_bits) + (b >> 6), 1ull << (b & 63));
-                if (mask_bytes != nullptr) mask_bytes[b] = 1;
+            double tc = 0.0;
+            if (live) {
+                build_core(m, ra, TA, A);
+                build_core(m, rb, TB, Bc);
+                const double* cst = m.vp_cst + 4 * p;
+                int verdict;
+                if (Bc.kind == K_PLANE) verdict = plane_collides(A, Bc, thr, cst[2]) ? 1 : 0;
+                else { tc = (thr + cst[0]) + cst[1]; verdict = cores_collide_pre(A, Bc, tc); }
+                if (verdict == 1) mark_hit(b, mask_bits, mask_bytes);
+                pooled = verdict < 0;
+            }
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pooled);
+            if (bal != 0ull) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&pool_n, __builtin_popcountll(bal));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (pooled) {
+                    const int slot = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    pool_put(pool, slot, A, Bc, tc, b);
+                }
             }
         }
+        __syncthreads();
+        // ---- phase 2 -----------------------------------------------------------------------------------------------
+        {
+            const int np = pool_n;
+            bool have = false;
+            Core A, Bc;
+            GjkPred g;
+            double tc = 0.0;
+            long long b = 0;
+            A.kind = K_POINT; Bc.kind = K_POINT;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { A.c[e] = 0.0; Bc.c[e] = 1.0; A.h[e] = 0.0; Bc.h[e] = 0.0; A.ax[0][e] = A.ax[1][e] = A.ax[2][e] = 0.0; Bc.ax[0][e] = Bc.ax[1][e] = Bc.ax[2][e] = 0.0; }
+            A.rad = Bc.rad = A.margin = Bc.margin = A.rho = Bc.rho = 0.0;
+            gjk_pred_init(g, A, Bc);
+            while (true) {
+                // idle lanes take the next pooled items (one LDS atomic per wave and trip)
+                const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
+                if (idle != 0ull) {
+                    int first = 0;
+                    if (lane == 0) first = atomicAdd(&pool_next, __builtin_popcountll(idle));
+                    first = __builtin_amdgcn_readfirstlane(first);
+                    if (!have) {
+                        const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                        if (slot < np) {
+                            pool_get(pool, slot, A, Bc, tc, b);
+                            gjk_pred_init(g, A, Bc);
+                            have = true;
+                        }
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+                if (have) {
+                    const int r = gjk_pred_step(g, A, Bc, tc);
+                    if (r != 0) {
+                        if (r == 2) mark_hit(b, mask_bits, mask_bytes);
+                        have = false;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1725,7 +1845,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         else
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 8), dim3(256), 0, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
+        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 16), dim3(NARROW_T), 0, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
                            mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
         NBK_HIP(hipGetLastError());
     }

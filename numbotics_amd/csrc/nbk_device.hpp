@@ -420,43 +420,77 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
 
 // GJK predicate: dist(coreA, coreB) < tc ?  Same iteration, but it returns as soon as the support-plane
 // lower bound reaches tc (free) or the simplex point drops below tc (colliding).
-NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
+// The predicate as a resumable state machine: gjk_pred_init once, then gjk_pred_step until it returns non-zero
+// (1 = free, 2 = colliding).  One step = one GJK iteration.  k_narrow advances all its lanes one step at a time
+// and hands a finished lane the next queued item, so the lanes of a wave stay busy although the iteration
+// counts of the items differ (mean 2.2, max ~8 on the benchmark scene); gjk_collides below is the plain loop.
+struct GjkPred {
     Simplex<false> sx;
-    sx_init<false>(sx);
     double v[3];
-    sub3(A.c, Bc.c, v);
-    if (dot3(v, v) == 0.0) { v[0] = 1.0; v[1] = 0.0; v[2] = 0.0; }
-    double vv_prev = NBK_INF, lb2 = 0.0;
+    double vv_prev, lb2;
+    bool sep;
+    int it;
+};
+
+NBK_DEV void gjk_pred_init(GjkPred& g, const Core& A, const Core& Bc) {
+    sx_init<false>(g.sx);
+    sub3(A.c, Bc.c, g.v);
+    if (dot3(g.v, g.v) == 0.0) { g.v[0] = 1.0; g.v[1] = 0.0; g.v[2] = 0.0; }
+    g.vv_prev = NBK_INF;
+    g.lb2 = 0.0;
+    g.sep = false;
+    g.it = 0;
+}
+
+NBK_DEV int gjk_pred_step(GjkPred& g, const Core& A, const Core& Bc, double tc) {
     const double tc2 = tc * tc;
-    bool sep = false;
-    for (int it = 0; it < GJK_MAXIT; ++it) {
-        const double nv[3] = {-v[0], -v[1], -v[2]};
+    bool finish = g.it >= GJK_MAXIT;       // out of iterations: decide on the current simplex point
+    if (!finish) {
+        const double nv[3] = {-g.v[0], -g.v[1], -g.v[2]};
         double sa[3], sb[3], w[3];
         core_support(A, nv, sa);
-        core_support(Bc, v, sb);
+        core_support(Bc, g.v, sb);
         sub3(sa, sb, w);
-        const double vv = dot3(v, v);
-        const double vw = dot3(v, w);
+        const double vv = dot3(g.v, g.v);
+        const double vw = dot3(g.v, w);
         if (vw > 0.0) {
-            sep = true;
-            if (tc <= 0.0) return false;
-            if (vw * vw >= tc2 * vv) return false;
+            g.sep = true;
+            if (tc <= 0.0) return 1;
+            if (vw * vw >= tc2 * vv) return 1;
             const double l2 = (vw * vw) / vv;
-            if (l2 > lb2) lb2 = l2;
+            if (l2 > g.lb2) g.lb2 = l2;
         }
-        if (sx.n > 0 && (vv - lb2) <= GJK_EPS_REL * vv) break;
-        if (sx_has<false>(sx, w)) break;
-        const int st = gjk_advance<false>(sx, w, sa, sb, v, vv_prev);
-        if (st == 1) {
-            if (sep) break;
-            if (tc >= 0.0) return true;
-            double nrm[3];
-            return -overlap_depth(A, Bc, nrm) < tc;
+        if (g.sx.n > 0 && (vv - g.lb2) <= GJK_EPS_REL * vv) finish = true;
+        else if (sx_has<false>(g.sx, w)) finish = true;
+        else {
+            const int st = gjk_advance<false>(g.sx, w, sa, sb, g.v, g.vv_prev);
+            if (st == 1) {
+                if (g.sep) finish = true;
+                else {
+                    if (tc >= 0.0) return 2;
+                    double nrm[3];
+                    return (-overlap_depth(A, Bc, nrm) < tc) ? 2 : 1;
+                }
+            } else if (st == 2) finish = true;
+            else {
+                if (tc > 0.0 && g.vv_prev < tc2) return 2;
+                g.it += 1;
+                return 0;
+            }
         }
-        if (st == 2) break;
-        if (tc > 0.0 && vv_prev < tc2) return true;
     }
-    return nbk_sqrt(dot3(v, v)) < tc;
+    return (nbk_sqrt(dot3(g.v, g.v)) < tc) ? 2 : 1;
+}
+
+NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
+
+NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
+    GjkPred g;
+    gjk_pred_init(g, A, Bc);
+    while (true) {
+        const int r = gjk_pred_step(g, A, Bc, tc);
+        if (r != 0) return r == 2;
+    }
 }
 
 // ---- overlap depth over the candidate axis family ---------------------------------------------
@@ -722,24 +756,31 @@ NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rh
     return (hc - core_halfwidth(A, Pl.ax[2])) < t;
 }
 
-// steps 4-5 of the predicate (box midphase, exact test): A/Bc already in canonical order, neither is a plane
-NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
+// steps 4-5 of the predicate up to (not including) GJK: 0 = free, 1 = colliding, -1 = the GJK predicate decides.
+// A/Bc already in canonical order, neither is a plane.
+NBK_DEV int cores_collide_pre(const Core& A, const Core& Bc, double tc) {
     // midphase for box cores: the other core's centre against the exact box (no square roots)
     if (A.kind == K_BOX || Bc.kind == K_BOX) {
         const bool b_is_box = Bc.kind == K_BOX;
         int verdict;
         if (b_is_box) verdict = box_midphase(A.c, A.rho, Bc, tc);
         else verdict = box_midphase(Bc.c, Bc.rho, A, tc);
-        if (verdict >= 0) return verdict != 0;
+        if (verdict >= 0) return verdict;
     }
     const bool a_ps = (A.kind == K_POINT || A.kind == K_SEG), b_ps = (Bc.kind == K_POINT || Bc.kind == K_SEG);
     if (a_ps && b_ps) {
         double pa[3], pb[3], e[3];
         ps_closest(A, Bc, pa, pb);
         sub3(pa, pb, e);
-        return nbk_sqrt(dot3(e, e)) < tc;
+        return (nbk_sqrt(dot3(e, e)) < tc) ? 1 : 0;
     }
-    if (A.kind == K_POINT) { double cp[3], nb[3]; return point_solid(A.c, Bc, cp, nb) < tc; }
+    if (A.kind == K_POINT) { double cp[3], nb[3]; return (point_solid(A.c, Bc, cp, nb) < tc) ? 1 : 0; }
+    return -1;
+}
+
+NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
+    const int pre = cores_collide_pre(A, Bc, tc);
+    if (pre >= 0) return pre != 0;
     return gjk_collides(A, Bc, tc);
 }
 
