@@ -120,7 +120,7 @@ def main():
     # ---- roofline of the dominant kernel (validity) ---------------------------------------------------
     alg_bytes = (hi - lo) * (8.0 * chain.dof) + n_words * 8.0
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, fk_traffic, traffic_src = None, None, None
+    traffic, fk_traffic, traffic_src, valu = None, None, None, None
     import glob
     side = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if side:
@@ -132,11 +132,13 @@ def main():
         traffic = tj["validity_step_hbm_bytes"] * scale
         fk_traffic = tj["kernels"]["k_fk"]["hbm_bytes_corrected"] * scale
         traffic_src = os.path.relpath(side[-1], ROOT)
+        valu = tj.get("sq")
     roofline = {"bound": "hbm", "kernel": "k_broad + k_narrow (one nbk_validity_batch call)" if (hi - lo) >= 8192 else "k_validity",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
                 "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_config": 8.0 * chain.dof + 0.125,
-                "note": "VALU-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md"}
+                "note": "VALU-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md",
+                "valu": valu}
 
     # ---- the HBM-bound kernel of the path: pose-writing FK of one frame -------------------------------
     T = arm.forward_kinematics(q, "tool_frame")
