@@ -1060,7 +1060,7 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
 //   phase 2 (dynamic): every lane runs the GJK predicate ONE iteration per trip and, when its item is decided,
 //            takes the next pooled item -- iteration counts differ a lot between items (mean 2.2, max ~8), so a
 //            static item-to-lane assignment leaves two thirds of the lanes idle.
-constexpr int NARROW_T = 128;
+constexpr int NARROW_T = 64;
 constexpr int POOL_E = 36;
 
 NBK_DEV void pool_put(double* pool, int slot, const Core& A, const Core& Bc, double tc, long long b) {
@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
     __shared__ double pool[POOL_E * NARROW_T];
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
     __shared__ int pool_n, pool_next;
     // block (sub, part): every nparts-th 128-item chunk of sub-queue `sub`
     const unsigned sub = blockIdx.x % NSUB;
@@ -1153,25 +1154,27 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
             Xf TA, TB;
             xf_from12(m.base_pose, TA);
             TB = TA;
-            const double* qrow = q + b * m.n_q;
-            const double* grow = qrow;
-            double et = 0.0, eomt = 0.0;
-            const bool edge = es.map != nullptr;
-            if (edge && live) {
-                unsigned e;
-                et = edge_t(es, es.map[b], e);
-                eomt = 1.0 - et;
-                qrow = es.starts + (size_t)e * m.n_q;
-                grow = es.goals + (size_t)e * m.n_q;
+            // this lane's q row goes to LDS first: all its loads are in flight at once, instead of one global
+            // round trip per joint inside the loop below (the kernel is latency-bound)
+            double* myq = qstage + threadIdx.x * m.n_q;
+            if (live) {
+                if (es.map != nullptr) {
+                    unsigned e;
+                    const double et = edge_t(es, es.map[b], e);
+                    const double eomt = 1.0 - et;
+                    const double* sp = es.starts + (size_t)e * m.n_q;
+                    const double* gp = es.goals + (size_t)e * m.n_q;
+                    for (int j = 0; j < m.n_q; ++j) { const double a = eomt * sp[j]; const double bb = et * gp[j]; myq[j] = a + bb; }
+                } else {
+                    const double* qrow = q + b * m.n_q;
+                    for (int j = 0; j < m.n_q; ++j) myq[j] = qrow[j];
+                }
             }
             for (int k = 0; k < m.n_joints; ++k) {
                 const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
                 if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
                 if (in_a || in_b) {
-                    const int qi = m.joint_qidx[k];
-                    double qk;
-                    if (edge) { const double a = eomt * qrow[qi]; const double bb = et * grow[qi]; qk = a + bb; }
-                    else qk = qrow[qi];
+                    const double qk = myq[m.joint_qidx[k]];
                     Xf nxt;
                     joint_apply(m, k, in_a ? TA : TB, qk, nxt);     // common ancestors: TA == TB bit for bit
                     if (in_a) TA = nxt;
@@ -1205,10 +1208,11 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
         __syncthreads();
         // ---- phase 2 -----------------------------------------------------------------------------------------------
         {
-            const int np = pool_n;
+            const int np = (m.dbg & 8) ? 0 : pool_n;
             bool have = false;
             Core A, Bc;
             GjkPred g;
+            GjkBool gb;
             double tc = 0.0;
             long long b = 0;
             A.kind = K_POINT; Bc.kind = K_POINT;
@@ -1216,6 +1220,7 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
             for (int e = 0; e < 3; ++e) { A.c[e] = 0.0; Bc.c[e] = 1.0; A.h[e] = 0.0; Bc.h[e] = 0.0; A.ax[0][e] = A.ax[1][e] = A.ax[2][e] = 0.0; Bc.ax[0][e] = Bc.ax[1][e] = Bc.ax[2][e] = 0.0; }
             A.rad = Bc.rad = A.margin = Bc.margin = A.rho = Bc.rho = 0.0;
             gjk_pred_init(g, A, Bc);
+            gjkb_init(gb, A, Bc);
             while (true) {
                 // idle lanes take the next pooled items (one LDS atomic per wave and trip)
                 const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
@@ -1227,14 +1232,14 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
                         const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
                         if (slot < np) {
                             pool_get(pool, slot, A, Bc, tc, b);
-                            gjk_pred_init(g, A, Bc);
+                            if (tc == 0.0) gjkb_init(gb, A, Bc); else gjk_pred_init(g, A, Bc);
                             have = true;
                         }
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
                 if (have) {
-                    const int r = gjk_pred_step(g, A, Bc, tc);
+                    const int r = (tc == 0.0) ? gjkb_step(gb, A, Bc) : gjk_pred_step(g, A, Bc, tc);
                     if (r != 0) {
                         if (r == 2) mark_hit(b, mask_bits, mask_bytes);
                         have = false;
@@ -1845,7 +1850,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         else
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 16), dim3(NARROW_T), 0, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
+        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 32), dim3(NARROW_T), sizeof(double) * NARROW_T * (size_t)m->n_q, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
                            mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
         NBK_HIP(hipGetLastError());
     }

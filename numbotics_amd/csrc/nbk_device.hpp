@@ -493,6 +493,104 @@ NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
     }
 }
 
+// ---- boolean GJK (the predicate for tc == 0): mirrors gjk_intersect of the oracle ------------------------------
+constexpr int GJKB_MAXIT = 32;
+struct GjkBool { double p[3][3]; int n; double d[3]; int it; };   // p[0] oldest; at most 3 points are kept between steps
+
+NBK_DEV void mink_support(const Core& A, const Core& Bc, const double* d, double* w) {
+    const double nd[3] = {-d[0], -d[1], -d[2]};
+    double sa[3], sb[3];
+    core_support(A, d, sa);
+    core_support(Bc, nd, sb);
+    sub3(sa, sb, w);
+}
+NBK_DEV void tri_prod(const double* x, const double* y, double* o) {   // (x cross y) cross x
+    double t[3];
+    cross3(x, y, t);
+    cross3(t, x, o);
+}
+NBK_DEV void gjkb_triangle(GjkBool& g, const double* c_in, const double* b_in, const double* a_in) {
+    const double c[3] = {c_in[0], c_in[1], c_in[2]}, b[3] = {b_in[0], b_in[1], b_in[2]}, a[3] = {a_in[0], a_in[1], a_in[2]};
+    double ab[3], ac[3], abc[3], t[3];
+    const double ao[3] = {-a[0], -a[1], -a[2]};
+    sub3(b, a, ab); sub3(c, a, ac);
+    cross3(ab, ac, abc);
+    cross3(abc, ac, t);
+    bool star = false;
+    if (dot3(t, ao) > 0.0) {
+        if (dot3(ac, ao) > 0.0) {
+            copy3(c, g.p[0]); copy3(a, g.p[1]); g.n = 2;
+            tri_prod(ac, ao, g.d);
+            return;
+        }
+        star = true;
+    } else {
+        cross3(ab, abc, t);
+        if (dot3(t, ao) > 0.0) star = true;
+    }
+    if (star) {
+        if (dot3(ab, ao) > 0.0) { copy3(b, g.p[0]); copy3(a, g.p[1]); g.n = 2; tri_prod(ab, ao, g.d); }
+        else { copy3(a, g.p[0]); g.n = 1; copy3(ao, g.d); }
+        return;
+    }
+    if (dot3(abc, ao) > 0.0) {
+        copy3(c, g.p[0]); copy3(b, g.p[1]); copy3(a, g.p[2]);
+        copy3(abc, g.d);
+    } else {
+        copy3(b, g.p[0]); copy3(c, g.p[1]); copy3(a, g.p[2]);
+        g.d[0] = -abc[0]; g.d[1] = -abc[1]; g.d[2] = -abc[2];
+    }
+    g.n = 3;
+}
+NBK_DEV void gjkb_init(GjkBool& g, const Core& A, const Core& Bc) {
+    sub3(A.c, Bc.c, g.d);
+    if (dot3(g.d, g.d) == 0.0) { g.d[0] = 1.0; g.d[1] = 0.0; g.d[2] = 0.0; }
+    g.n = 0;
+    g.it = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { g.p[i][0] = 0.0; g.p[i][1] = 0.0; g.p[i][2] = 0.0; }
+}
+// one iteration: 0 = continue, 1 = free, 2 = intersecting
+NBK_DEV int gjkb_step(GjkBool& g, const Core& A, const Core& Bc) {
+    if (g.it >= GJKB_MAXIT) return 2;
+    double a[3];
+    mink_support(A, Bc, g.d, a);
+    if (dot3(a, g.d) < 0.0) return 1;
+    g.it += 1;
+    if (g.n == 0) {
+        copy3(a, g.p[0]); g.n = 1;
+        g.d[0] = -a[0]; g.d[1] = -a[1]; g.d[2] = -a[2];
+    } else if (g.n == 1) {
+        double ab[3];
+        const double ao[3] = {-a[0], -a[1], -a[2]};
+        sub3(g.p[0], a, ab);
+        if (dot3(ab, ao) > 0.0) { copy3(a, g.p[1]); g.n = 2; tri_prod(ab, ao, g.d); }
+        else { copy3(a, g.p[0]); g.n = 1; copy3(ao, g.d); }
+    } else if (g.n == 2) {
+        gjkb_triangle(g, g.p[0], g.p[1], a);
+    } else {
+        double ab[3], ac[3], ad[3], abc[3], acd[3], adb[3];
+        const double ao[3] = {-a[0], -a[1], -a[2]};
+        const double dd[3] = {g.p[0][0], g.p[0][1], g.p[0][2]}, c[3] = {g.p[1][0], g.p[1][1], g.p[1][2]}, b[3] = {g.p[2][0], g.p[2][1], g.p[2][2]};
+        sub3(b, a, ab); sub3(c, a, ac); sub3(dd, a, ad);
+        cross3(ab, ac, abc); cross3(ac, ad, acd); cross3(ad, ab, adb);
+        const double sabc = dot3(abc, ad) > 0.0 ? -1.0 : 1.0;
+        const double sacd = dot3(acd, ab) > 0.0 ? -1.0 : 1.0;
+        const double sadb = dot3(adb, ac) > 0.0 ? -1.0 : 1.0;
+        if (sabc * dot3(abc, ao) > 0.0) gjkb_triangle(g, c, b, a);
+        else if (sacd * dot3(acd, ao) > 0.0) gjkb_triangle(g, dd, c, a);
+        else if (sadb * dot3(adb, ao) > 0.0) gjkb_triangle(g, b, dd, a);
+        else return 2;
+    }
+    if (dot3(g.d, g.d) == 0.0) return 2;
+    return 0;
+}
+NBK_DEV bool gjk_intersect(const Core& A, const Core& Bc) {
+    GjkBool g;
+    gjkb_init(g, A, Bc);
+    while (true) { const int r = gjkb_step(g, A, Bc); if (r != 0) return r == 2; }
+}
+
 // ---- overlap depth over the candidate axis family ---------------------------------------------
 NBK_DEV void try_axis(const Core& A, const Core& Bc, const double* delta, const double* n_in, double& best, double* bn) {
     const double nn = dot3(n_in, n_in);
@@ -781,6 +879,7 @@ NBK_DEV int cores_collide_pre(const Core& A, const Core& Bc, double tc) {
 NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
     const int pre = cores_collide_pre(A, Bc, tc);
     if (pre >= 0) return pre != 0;
+    if (tc == 0.0) return gjk_intersect(A, Bc);       // pure intersection test: the boolean walk
     return gjk_collides(A, Bc, tc);
 }
 

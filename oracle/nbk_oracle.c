@@ -749,6 +749,113 @@ static double cores_distance(const core_t *A, const core_t *Bc, double *wit, int
     return dist;
 }
 
+/* ---- boolean GJK: do two cores intersect?  (the predicate for tc == 0) ----------------------------------------
+ * No closest points, only a walk of the simplex towards the origin of the Minkowski difference M = A (-) B:
+ * a support point a with a.d < 0 proves a separating direction (free); a tetrahedron around the origin, or the
+ * origin on the simplex, is an intersection.  Undecided after the cap (grazing contact of curved cores) counts
+ * as touching.  About five times cheaper per iteration than the distance iteration, which matters because most
+ * items that reach this stage are penetrations (>= 4 iterations). */
+#define GJKB_MAXIT 32
+typedef struct { double p[4][3]; int n; double d[3]; int it; } gjkb_t;
+
+static void mink_support(const core_t *A, const core_t *Bc, const double *d, double *w) {
+    double nd[3] = {-d[0], -d[1], -d[2]}, sa[3], sb[3];
+    core_support(A, d, sa);
+    core_support(Bc, nd, sb);
+    sub3(sa, sb, w);
+}
+static void tri_prod(const double *x, const double *y, double *o) { /* (x cross y) cross x */
+    double t[3];
+    cross3(x, y, t);
+    cross3(t, x, o);
+}
+/* triangle (c oldest, b, a newest): new simplex and direction.  keeps points in g->p[0..n) oldest first */
+static void gjkb_triangle(gjkb_t *g, const double *c, const double *b, const double *a) {
+    double ab[3], ac[3], ao[3] = {-a[0], -a[1], -a[2]}, abc[3], t[3];
+    sub3(b, a, ab); sub3(c, a, ac);
+    cross3(ab, ac, abc);
+    cross3(abc, ac, t);
+    int star = 0;
+    if (dot3(t, ao) > 0.0) {
+        if (dot3(ac, ao) > 0.0) {
+            double cc[3] = {c[0], c[1], c[2]}, aa[3] = {a[0], a[1], a[2]};
+            memcpy(g->p[0], cc, 24); memcpy(g->p[1], aa, 24); g->n = 2;
+            tri_prod(ac, ao, g->d);
+            return;
+        }
+        star = 1;
+    } else {
+        cross3(ab, abc, t);
+        if (dot3(t, ao) > 0.0) star = 1;
+    }
+    if (star) {
+        double bb[3] = {b[0], b[1], b[2]}, aa[3] = {a[0], a[1], a[2]};
+        if (dot3(ab, ao) > 0.0) { memcpy(g->p[0], bb, 24); memcpy(g->p[1], aa, 24); g->n = 2; tri_prod(ab, ao, g->d); }
+        else { memcpy(g->p[0], aa, 24); g->n = 1; g->d[0] = ao[0]; g->d[1] = ao[1]; g->d[2] = ao[2]; }
+        return;
+    }
+    {
+        double cc[3] = {c[0], c[1], c[2]}, bb[3] = {b[0], b[1], b[2]}, aa[3] = {a[0], a[1], a[2]};
+        if (dot3(abc, ao) > 0.0) {
+            memcpy(g->p[0], cc, 24); memcpy(g->p[1], bb, 24); memcpy(g->p[2], aa, 24);
+            g->d[0] = abc[0]; g->d[1] = abc[1]; g->d[2] = abc[2];
+        } else {
+            memcpy(g->p[0], bb, 24); memcpy(g->p[1], cc, 24); memcpy(g->p[2], aa, 24);
+            g->d[0] = -abc[0]; g->d[1] = -abc[1]; g->d[2] = -abc[2];
+        }
+        g->n = 3;
+    }
+}
+
+static void gjkb_init(gjkb_t *g, const core_t *A, const core_t *Bc) {
+    sub3(A->c, Bc->c, g->d);
+    if (dot3(g->d, g->d) == 0.0) { g->d[0] = 1.0; g->d[1] = 0.0; g->d[2] = 0.0; }
+    g->n = 0;
+    g->it = 0;
+}
+/* one iteration: 0 = continue, 1 = free, 2 = intersecting */
+static int gjkb_step(gjkb_t *g, const core_t *A, const core_t *Bc) {
+    if (g->it >= GJKB_MAXIT) return 2;
+    double a[3];
+    mink_support(A, Bc, g->d, a);
+    if (dot3(a, g->d) < 0.0) return 1;
+    g->it += 1;
+    if (g->n == 0) {
+        memcpy(g->p[0], a, 24); g->n = 1;
+        g->d[0] = -a[0]; g->d[1] = -a[1]; g->d[2] = -a[2];
+    } else if (g->n == 1) {
+        double b[3], ab[3], ao[3] = {-a[0], -a[1], -a[2]};
+        memcpy(b, g->p[0], 24);
+        sub3(b, a, ab);
+        if (dot3(ab, ao) > 0.0) { memcpy(g->p[1], a, 24); g->n = 2; tri_prod(ab, ao, g->d); }
+        else { memcpy(g->p[0], a, 24); g->n = 1; g->d[0] = ao[0]; g->d[1] = ao[1]; g->d[2] = ao[2]; }
+    } else if (g->n == 2) {
+        double c[3], b[3];
+        memcpy(c, g->p[0], 24); memcpy(b, g->p[1], 24);
+        gjkb_triangle(g, c, b, a);
+    } else {
+        double dd[3], c[3], b[3], ab[3], ac[3], ad[3], ao[3] = {-a[0], -a[1], -a[2]}, abc[3], acd[3], adb[3];
+        memcpy(dd, g->p[0], 24); memcpy(c, g->p[1], 24); memcpy(b, g->p[2], 24);
+        sub3(b, a, ab); sub3(c, a, ac); sub3(dd, a, ad);
+        cross3(ab, ac, abc); cross3(ac, ad, acd); cross3(ad, ab, adb);
+        /* outward normals: away from the opposite vertex */
+        const double sabc = dot3(abc, ad) > 0.0 ? -1.0 : 1.0;
+        const double sacd = dot3(acd, ab) > 0.0 ? -1.0 : 1.0;
+        const double sadb = dot3(adb, ac) > 0.0 ? -1.0 : 1.0;
+        if (sabc * dot3(abc, ao) > 0.0) gjkb_triangle(g, c, b, a);
+        else if (sacd * dot3(acd, ao) > 0.0) gjkb_triangle(g, dd, c, a);
+        else if (sadb * dot3(adb, ao) > 0.0) gjkb_triangle(g, b, dd, a);
+        else return 2;
+    }
+    if (dot3(g->d, g->d) == 0.0) return 2;      /* the origin lies on the simplex */
+    return 0;
+}
+static int gjk_intersect(const core_t *A, const core_t *Bc) {
+    gjkb_t g;
+    gjkb_init(&g, A, Bc);
+    for (;;) { const int r = gjkb_step(&g, A, Bc); if (r) return r == 2; }
+}
+
 /* bounding radius of a core about its centre (broadphase) */
 static double core_bound_radius(const core_t *s) {
     switch (s->kind) {
@@ -772,7 +879,8 @@ static __thread long long g_stat_items = 0, g_stat_survive = 0, g_stat_gjk = 0; 
  *   4. midphase when a box core is involved, on the OTHER core's centre c (a point of that core), without
  *      square roots: d2 = squared distance of c to the box; outside: d2 >= (tc + rho_other)^2 (tc >= 0) => free,
  *      d2 < tc^2 (tc > 0) => colliding; inside at depth g: -g < tc => colliding;
- *   5. exact test: closed form for point/segment cores and point-vs-solid, GJK predicate otherwise. */
+ *   5. exact test: closed form for point/segment cores and point-vs-solid; otherwise GJK -- the boolean walk
+ *      (gjk_intersect) when tc == 0, the distance iteration with early exits (gjk_collides) for any other tc. */
 static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     if (B0->kind == K_PLANE) {
         double d[3];
@@ -829,6 +937,7 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     }
     if (A->kind == K_POINT) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
     g_stat_gjk++;
+    if (tc == 0.0) return gjk_intersect(A, Bc);      /* pure intersection test: the boolean walk */
     return gjk_collides(A, Bc, tc);
 }
 
