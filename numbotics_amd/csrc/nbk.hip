@@ -597,6 +597,12 @@ NBK_DEV void flush_items(unsigned* lds_queue, int qn, int64_t base_cfg, unsigned
     __syncthreads();
 }
 
+// the NSUB queue counters are cleared by a kernel of our own: a hipMemsetAsync node did not reliably clear them
+// when the call was replayed from a captured hipGraph (ROCm 7.2), a plain kernel node does
+__global__ void k_zero_counters(unsigned long long* __restrict__ q_count) {
+    q_count[threadIdx.x * CNT_STRIDE] = 0ull;
+}
+
 // LDS: raw q slab [64*n_q] | saved frames [12*slots][64] | centres [3*S][64] | pair constants [P][4] |
 //      world cores [W][18] | queue [BQ_CAP] u32.
 // Lane = configuration throughout.  Everything a pair needs that does not depend on the configuration
@@ -1128,7 +1134,8 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
     const unsigned sub = blockIdx.x % NSUB;
     const unsigned part = blockIdx.x / NSUB;
     const unsigned nparts = gridDim.x / NSUB;
-    unsigned long long n = q_count[sub * CNT_STRIDE];
+    // agent-scope loads: the queue was written by another kernel (possibly replayed from a hipGraph)
+    unsigned long long n = __hip_atomic_load(q_count + sub * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > cap) n = cap;
     if (m.dbg & 1) n = 0;
     q_items += (unsigned long long)sub * cap;
@@ -1141,7 +1148,7 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
             const unsigned long long i = i0 + threadIdx.x;
             const bool live = i < n;
             unsigned long long item = 0;
-            if (live) item = q_items[i];
+            if (live) item = __hip_atomic_load(q_items + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const long long b = (long long)(item >> 20);
             const int p = (int)(item & 0xFFFFFull);
             int ra = -1, rb = -1;
@@ -1834,7 +1841,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         const unsigned long long cap_sub = (unsigned long long)((nblk + NSUB - 1) / NSUB) * WAVE * (unsigned long long)m->n_pairs;
         EdgeSrc es_tile = es;
         if (es.map != nullptr) es_tile.map = es.map + b0;
-        NBK_HIP(hipMemsetAsync(count, 0, WS_HEADER, st));
+        hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count);
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
         const double* qt = q ? q + b0 * m->n_q : nullptr;
         uint64_t* mb = mask_bits ? mask_bits + b0 / 64 : nullptr;

@@ -386,3 +386,51 @@ def test_iris_inner_steps(fresh_world, torch_cuda):
                 lo_i = mid
         assert np.array_equal(hi_i, hi[i])
     assert np.asarray(arm.in_collision(hi, 1e-6)).all()          # the returned ends are still colliding
+
+
+def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
+    """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
+    capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
+    import ctypes as C
+    torch = torch_cuda
+    from numbotics_amd import _lib
+    arm, chain, obs = build_scene("c2")
+    _, dev = arm._scene_device()
+    lib = _lib.load()
+    q = torch.from_numpy(sample_q(chain, 20000, seed=3)).cuda()
+    words = torch.empty((313,), dtype=torch.int64, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.nbk_validity_batch(dev._h, q.data_ptr(), 20000, 0.0, None, None, st) == -1          # no output given
+    assert lib.nbk_validity_batch(None, q.data_ptr(), 20000, 0.0, words.data_ptr(), None, st) == -1
+    assert lib.nbk_validity_batch(dev._h, None, 20000, 0.0, words.data_ptr(), None, st) == -1
+    assert lib.nbk_validity_batch(dev._h, q.data_ptr(), -5, 0.0, words.data_ptr(), None, st) == -1
+    assert lib.nbk_validity_batch(dev._h, q.data_ptr(), 0, 0.0, words.data_ptr(), None, st) == 0           # empty batch
+    bad_path = (C.c_int32 * 2)(0, 99)
+    local = (C.c_double * 12)(1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0)
+    T = torch.empty((20000, 16), dtype=torch.float64, device="cuda")
+    assert lib.nbk_fk_batch(dev._h, q.data_ptr(), 20000, bad_path, 2, local, None, T.data_ptr(), st) == -1   # joint index out of range
+    assert lib.nbk_edge_validity_batch(dev._h, q.data_ptr(), q.data_ptr(), None, 10, -0.1, 1.0, 0, 0.0,
+                                       words.data_ptr(), None, None, st) == -1                               # bad resolution
+    assert lib.nbk_status_string(-1).decode() == "invalid argument"
+    # graph capture of the workspace variant
+    need = dev.validity_workspace_bytes(20000)
+    ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    ref = dev.validity(q, 0.0, packed=True).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sst = C.c_void_p(side.cuda_stream)
+        _lib.check(lib.nbk_validity_batch_ws(dev._h, q.data_ptr(), 20000, 0.0, words.data_ptr(), None, ws.data_ptr(), need, sst), "warm-up")
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        cst = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.nbk_validity_batch_ws(dev._h, q.data_ptr(), 20000, 0.0, words.data_ptr(), None, ws.data_ptr(), need, cst), "capture")
+    words.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(words, ref)
+    q.copy_(torch.from_numpy(sample_q(chain, 20000, seed=4)).cuda())        # new inputs, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(words, dev.validity(q, 0.0, packed=True))
