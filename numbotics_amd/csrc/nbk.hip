@@ -1300,6 +1300,176 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     }
 }
 
+// ---- closest pair with branch-and-bound ----------------------------------------------------------------------
+// min over the allowed pairs of the exact signed distance, and the first pair attaining it.  Cheap bounds first:
+// with D = |cA - cB| (centres are points of the cores), D - (mA + mB) >= d_p >= D - (rhoA + rhoB) - (mA + mB),
+// so only pairs whose lower bound does not exceed the smallest upper bound U can be the minimum.  Those few
+// (lane, pair) items are compacted into an LDS queue and their exact distances (GJK converged to 1e-10) are
+// evaluated on full waves; every lane then reduces its own items (minimum, ties to the smallest pair index).
+// The result is exactly that of evaluating every pair (k_distances<0>): only work is skipped.
+constexpr int CQ_CAP = 512;
+
+NBK_DEV unsigned long long orderable(double d) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, d);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+NBK_DEV double from_orderable(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __builtin_bit_cast(double, u);
+}
+
+// D^2 (or the plane height hc) and the two constants R = rho sum + margin sum, M = margin sum of pair p for this lane
+NBK_DEV void closest_bounds(const DevModel& m, const double* lds_s, int p, int lane, double& dd, double& hc, bool& plane, double& R, double& M) {
+    const int a = m.pair_a[p], b = m.pair_b[p];
+    const double* ra = lds_s + m.rs_row[a] * WAVE + lane;
+    const double ca[3] = {ra[0], ra[WAVE], ra[2 * WAVE]};
+    const double mA = m.rs_core[6 * a + 4], rhoA = m.rs_core[6 * a + 5];
+    plane = false; hc = 0.0; dd = 0.0;
+    if (b < m.n_rshapes) {
+        const double* rb = lds_s + m.rs_row[b] * WAVE + lane;
+        const double d[3] = {ca[0] - rb[0], ca[1] - rb[WAVE], ca[2] - rb[2 * WAVE]};
+        dd = dot3(d, d);
+        M = mA + m.rs_core[6 * b + 4];
+        R = (rhoA + m.rs_core[6 * b + 5]) + M;
+    } else {
+        const int w = b - m.n_rshapes;
+        const double* wc = m.ws_core + 18 * w;
+        const double d[3] = {ca[0] - wc[0], ca[1] - wc[1], ca[2] - wc[2]};
+        if (m.ws_kind[w] == K_PLANE) {
+            const double n[3] = {wc[9], wc[10], wc[11]};
+            plane = true;
+            hc = dot3(d, n);
+            M = mA;
+            R = rhoA + mA;
+        } else {
+            dd = dot3(d, d);
+            M = mA + wc[16];
+            R = (rhoA + wc[17]) + M;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __restrict__ q, int64_t B,
+                                                 double* __restrict__ out_d, int32_t* __restrict__ out_i) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    double* lds_q = lds;
+    double* lds_s = lds_q + WAVE * m.n_q;
+    double* lds_fr = lds_s + WAVE * m.shape_rows;
+    double* lds_res = lds_fr + WAVE * 12 * m.frame_slots;                               // [CQ_CAP]
+    unsigned long long* lds_best = reinterpret_cast<unsigned long long*>(lds_res + CQ_CAP);   // [64]
+    unsigned* lds_arg = reinterpret_cast<unsigned*>(lds_best + WAVE);                   // [64]
+    unsigned* queue = lds_arg + WAVE;                                                    // [CQ_CAP]
+    stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
+    const int64_t b = base + lane;
+    const bool active = b < B;
+    sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
+    const int P = m.n_pairs;
+    if (P == 0) {
+        if (active) { out_d[b] = NBK_INF; if (out_i != nullptr) out_i[b] = -1; }
+        return;
+    }
+    // pass 1: smallest upper bound U0 and the pair with the smallest lower bound (float square roots, rounded
+    // outwards, are enough for bounds)
+    double U = NBK_INF, lb1 = NBK_INF;
+    int p1 = 0;
+    for (int p = 0; p < P; ++p) {
+        double dd, hc, R, M; bool plane;
+        closest_bounds(m, lds_s, p, lane, dd, hc, plane, R, M);
+        const float sf = __builtin_sqrtf((float)dd);
+        const double Dhi = plane ? hc : (double)(sf * 1.000001f + 1e-30f);
+        const double Dlo = plane ? hc : (double)(sf * 0.999999f);
+        const double ub = Dhi - M, lb = Dlo - R;
+        U = ub < U ? ub : U;
+        if (lb < lb1) { lb1 = lb; p1 = p; }
+    }
+    lds_best[lane] = ~0ull;
+    lds_arg[lane] = 0x7FFFFFFFu;
+    // round 1 (dense, one item per lane): the exact distance of that most promising pair tightens U a lot
+    queue[lane] = active ? (((unsigned)p1 << 6) | (unsigned)lane) : 0xFFFFFFFFu;
+    {
+        double d1 = NBK_INF;
+        if (active) {
+            const int a = m.pair_a[p1], bb = m.pair_b[p1];
+            Core A, Bc;
+            load_core_any(m, lds_s, a, lane, A);
+            load_core_any(m, lds_s, bb < m.n_rshapes ? bb : ~(bb - m.n_rshapes), lane, Bc);
+            d1 = cores_distance<false>(A, Bc, nullptr);
+            lds_best[lane] = orderable(d1);
+        }
+        lds_res[lane] = d1;
+        U = d1 < U ? d1 : U;
+    }
+    const double Ucut = U + (1e-9 + 1e-9 * __builtin_fabs(U));
+    // pass 2: the remaining candidates -> queue (slots 64..)
+    int qn = WAVE;
+    bool overflow = false;
+    for (int p = 0; p < P; ++p) {
+        double dd, hc, R, M; bool plane;
+        closest_bounds(m, lds_s, p, lane, dd, hc, plane, R, M);
+        bool cand;
+        if (plane) cand = (hc - R) <= Ucut;
+        else { const double t = Ucut + R; cand = (t >= 0.0) && (dd <= t * t); }
+        cand = cand && active && (p != p1);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(cand);
+        if (bal == 0ull) continue;
+        const int cnt = __builtin_popcountll(bal);
+        if (qn + cnt > CQ_CAP) { overflow = true; break; }
+        if (cand) {
+            const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            queue[pos] = ((unsigned)p << 6) | (unsigned)lane;
+        }
+        qn += cnt;
+    }
+    if (overflow) {
+        // (never seen on the test scenes) every pair, as k_distances<0> does
+        double best = NBK_INF;
+        int bi = -1;
+        for (int p = 0; p < P; ++p) {
+            Core A, Bc;
+            load_pair(m, lds_s, p, lane, A, Bc);
+            const double d = cores_distance<false>(A, Bc, nullptr);
+            const int u = m.pair_user[p];
+            if (d < best || (d == best && u < bi)) { best = d; bi = u; }
+        }
+        if (active) { out_d[b] = best; if (out_i != nullptr) out_i[b] = bi; }
+        return;
+    }
+    __syncthreads();
+    for (int i0 = WAVE; i0 < qn; i0 += WAVE) {
+        const int i = i0 + lane;
+        if (i < qn) {
+            const unsigned item = queue[i];
+            const int src = (int)(item & 63u), p = (int)(item >> 6);
+            const int a = m.pair_a[p], bb = m.pair_b[p];
+            Core A, Bc;
+            load_core_any(m, lds_s, a, src, A);
+            load_core_any(m, lds_s, bb < m.n_rshapes ? bb : ~(bb - m.n_rshapes), src, Bc);
+            const double d = cores_distance<false>(A, Bc, nullptr);
+            lds_res[i] = d;
+            atomicMin(&lds_best[src], orderable(d));
+        }
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < qn; i0 += WAVE) {
+        const int i = i0 + lane;
+        if (i < qn) {
+            const unsigned item = queue[i];
+            if (item != 0xFFFFFFFFu) {
+                const int src = (int)(item & 63u), p = (int)(item >> 6);
+                if (orderable(lds_res[i]) == lds_best[src]) atomicMin(&lds_arg[src], (unsigned)m.pair_user[p]);
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const unsigned long long k = lds_best[lane];
+        out_d[b] = (k == ~0ull) ? NBK_INF : from_orderable(k);
+        if (out_i != nullptr) out_i[b] = (k == ~0ull) ? -1 : (int32_t)lds_arg[lane];
+    }
+}
+
 // ---- DiscreteConnector: one edge per wave, lanes = interpolation samples ---------------------------
 __global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restrict__ starts, const double* __restrict__ goals,
                                                const double* __restrict__ dist, int64_t E, double resolution,
@@ -1910,8 +2080,14 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || min_dist == nullptr))) return NBK_ERR_INVALID;
     if (B == 0) return NBK_OK;
-    hipLaunchKernelGGL(k_distances<0>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, min_dist,
-                       argmin, (double*)nullptr);
+    static const bool brute = getenv("NBK_CLOSEST_BRUTE") != nullptr;
+    if (brute)
+        hipLaunchKernelGGL(k_distances<0>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, min_dist,
+                           argmin, (double*)nullptr);
+    else
+        hipLaunchKernelGGL(k_closest, dim3(blocks_for(B)), dim3(WAVE),
+                           collide_lds(m) - VALIDITY_LDS_EXTRA + sizeof(double) * CQ_CAP + 8 * WAVE + 4 * WAVE + 4 * CQ_CAP,
+                           (hipStream_t)stream, m->d, q, B, min_dist, argmin);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }
