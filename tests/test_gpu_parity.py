@@ -434,3 +434,24 @@ def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(words, dev.validity(q, 0.0, packed=True))
+
+
+def test_ten_million_batch_is_tiled_correctly(fresh_world, torch_cuda):
+    """BASELINE config 4 size on one GPU: 1e7 q run as several queue-sized tiles; the oracle on a strided slice
+    (which crosses every tile boundary) and the concatenation of two half batches give the same bits."""
+    torch = torch_cuda
+    from numbotics_amd.parallel import unpack_mask
+    arm, chain, obs = build_scene("c2")
+    _, dev = arm._scene_device()
+    orc = Oracle(arm.scene_model())
+    B = 10_000_000
+    qh = sample_q(chain, B, seed=7)
+    q = torch.from_numpy(qh).cuda()
+    assert dev.validity_workspace_bytes(B) <= (1 << 30)
+    w = dev.validity(q, 0.0, packed=True)
+    bits = unpack_mask(w.cpu().numpy(), B)
+    sl = np.arange(0, B, 211)
+    assert np.array_equal(bits[sl], orc.validity(qh[sl], 0.0, nthreads=16))
+    half = 5_000_000 - 5_000_000 % 64
+    w2 = torch.cat([dev.validity(q[:half], 0.0, packed=True), dev.validity(q[half:], 0.0, packed=True)])
+    assert torch.equal(w, w2)
