@@ -23,6 +23,15 @@ def test_capi_exports_every_declared_symbol():
     assert lib.nbk_device_count() >= 0
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/nbk.h must be consumable by a C compiler (cgo / JNI / ctypes generators read it as C)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "nbk.h"\nint main(void) { nbk_model_desc d; (void)d; return NBK_ABI_VERSION == 1 ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                   check=True)
+
+
 def test_device_path_fails_loudly_without_gpu(kinova):
     import torch
     if torch.cuda.is_available():
