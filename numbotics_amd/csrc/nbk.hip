@@ -59,10 +59,12 @@ struct DevModel {
     int n_plane_pairs, n_closed_pairs;   // class boundaries inside the sorted tables
     const int* rs_frame;          // [S] moving frame of each robot shape (frame order, non-decreasing)
     const unsigned* rs_mask;      // [S] joints on the path from the base to the shape's frame (bit k = joint k)
+    const int4* vp_info;          // [P] canonical refs and their joint masks in one 16-byte record: ra, rb, mask(ra), mask(rb)
     int bq_count[4];              // pairs per broadphase category
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
                                   //        index into the vp_* tables, category (0 plane, 1 robot-robot, 2 robot-world, 3 robot-world box)
-    int dbg;                              // ablation switches for profiling builds (NBK_ABLATE env): 1 = no narrowphase, 2 = no pair loop
+    int dbg;                              // ablation switches for profiling runs (NBK_ABLATE env): 1 = no narrowphase, 2 = no pair loop,
+                                          // 4 = no queue appends, 8 = no GJK phase, 16 = no FK replay, 32 = no cores, 64 = no pre-check
 };
 
 }  // namespace nbk
@@ -86,6 +88,7 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
+    bool margins_zero;        // every pair has mA = mB = 0: with threshold 0 the contact threshold tc is 0 for every pair
     // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
     void* ws;
     size_t ws_bytes;
@@ -1068,7 +1071,11 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
 //            static item-to-lane assignment leaves two thirds of the lanes idle.
 constexpr int NARROW_T = 64;
 constexpr int POOL_E = 36;
+constexpr int NARROW_WAVES_BOOL = 2;     // waves per SIMD the boolean-only narrowphase is compiled for (3 fits only with ~120 spilled
+                                         // registers and a 32-slot pool: measured no faster)
+constexpr int POOL_CAP_BOOL = NARROW_T;  // pool slots of the boolean-only kernel (fewer slots = less LDS; overflow is then decided in place)
 
+template <int STRIDE>
 NBK_DEV void pool_put(double* pool, int slot, const Core& A, const Core& Bc, double tc, long long b) {
     double* p = pool + slot;
     const Core* cs[2] = {&A, &Bc};
@@ -1078,23 +1085,24 @@ NBK_DEV void pool_put(double* pool, int slot, const Core& A, const Core& Bc, dou
         const int e0 = 17 * c;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            p[(e0 + e) * NARROW_T] = o.c[e];
-            p[(e0 + 3 + e) * NARROW_T] = o.ax[0][e];
-            p[(e0 + 6 + e) * NARROW_T] = o.ax[1][e];
-            p[(e0 + 9 + e) * NARROW_T] = o.ax[2][e];
-            p[(e0 + 12 + e) * NARROW_T] = o.h[e];
+            p[(e0 + e) * STRIDE] = o.c[e];
+            p[(e0 + 3 + e) * STRIDE] = o.ax[0][e];
+            p[(e0 + 6 + e) * STRIDE] = o.ax[1][e];
+            p[(e0 + 9 + e) * STRIDE] = o.ax[2][e];
+            p[(e0 + 12 + e) * STRIDE] = o.h[e];
         }
-        p[(e0 + 15) * NARROW_T] = o.rad;
-        p[(e0 + 16) * NARROW_T] = o.margin;
+        p[(e0 + 15) * STRIDE] = o.rad;
+        p[(e0 + 16) * STRIDE] = o.margin;
     }
-    p[34 * NARROW_T] = tc;
+    p[34 * STRIDE] = tc;
     const unsigned long long packed = ((unsigned long long)b << 8) | ((unsigned long long)(unsigned)A.kind << 4) | (unsigned long long)(unsigned)Bc.kind;
-    p[35 * NARROW_T] = __builtin_bit_cast(double, packed);
+    p[35 * STRIDE] = __builtin_bit_cast(double, packed);
 }
 
+template <int STRIDE>
 NBK_DEV void pool_get(const double* pool, int slot, Core& A, Core& Bc, double& tc, long long& b) {
     const double* p = pool + slot;
-    const unsigned long long packed = __builtin_bit_cast(unsigned long long, p[35 * NARROW_T]);
+    const unsigned long long packed = __builtin_bit_cast(unsigned long long, p[35 * STRIDE]);
     b = (long long)(packed >> 8);
     A.kind = (int)((packed >> 4) & 15ull);
     Bc.kind = (int)(packed & 15ull);
@@ -1105,17 +1113,17 @@ NBK_DEV void pool_get(const double* pool, int slot, Core& A, Core& Bc, double& t
         const int e0 = 17 * c;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            o.c[e] = p[(e0 + e) * NARROW_T];
-            o.ax[0][e] = p[(e0 + 3 + e) * NARROW_T];
-            o.ax[1][e] = p[(e0 + 6 + e) * NARROW_T];
-            o.ax[2][e] = p[(e0 + 9 + e) * NARROW_T];
-            o.h[e] = p[(e0 + 12 + e) * NARROW_T];
+            o.c[e] = p[(e0 + e) * STRIDE];
+            o.ax[0][e] = p[(e0 + 3 + e) * STRIDE];
+            o.ax[1][e] = p[(e0 + 6 + e) * STRIDE];
+            o.ax[2][e] = p[(e0 + 9 + e) * STRIDE];
+            o.h[e] = p[(e0 + 12 + e) * STRIDE];
         }
-        o.rad = p[(e0 + 15) * NARROW_T];
-        o.margin = p[(e0 + 16) * NARROW_T];
+        o.rad = p[(e0 + 15) * STRIDE];
+        o.margin = p[(e0 + 16) * STRIDE];
         o.rho = 0.0;
     }
-    tc = p[34 * NARROW_T];
+    tc = p[34 * STRIDE];
 }
 
 NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
@@ -1123,22 +1131,28 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
     if (mask_bytes != nullptr) mask_bytes[b] = 1;
 }
 
-__global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
-                                                 const unsigned long long* __restrict__ q_items,
-                                                 const unsigned long long* __restrict__ q_count, unsigned long long cap,
-                                                 uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
-    __shared__ double pool[POOL_E * NARROW_T];
-    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    __shared__ int pool_n, pool_next;
+// BOOL_ONLY: the host has established tc == 0 for every pair (threshold 0, no margins -- the reference's default
+// in_collision(q) call); only the boolean GJK state is kept, which removes the register spills of the general form.
+template <bool BOOL_ONLY, int POOL_CAP>
+NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
+                         const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
+                         unsigned long long cap, uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+                         double* pool, double* qstage, int& pool_n, int& pool_next) {
     // block (sub, part): every nparts-th 128-item chunk of sub-queue `sub`
     const unsigned sub = blockIdx.x % NSUB;
     const unsigned part = blockIdx.x / NSUB;
     const unsigned nparts = gridDim.x / NSUB;
-    // agent-scope loads: the queue was written by another kernel (possibly replayed from a hipGraph)
+    // agent-scope loads: the queue was written by another kernel (possibly replayed from a hipGraph).
+    // The kernel is latency-bound, so dependent global round trips are kept to three: {count, first item} ->
+    // {pair record, q row} -> shape constants.  The first chunk's item is loaded before the count is known (the slot
+    // is inside the allocated sub-queue either way; its value is used only when the slot is below the count).
+    q_items += (unsigned long long)sub * cap;
+    const unsigned long long i_first = (unsigned long long)part * NARROW_T + threadIdx.x;
+    unsigned long long item_first = 0;
+    if (i_first < cap) item_first = __hip_atomic_load(q_items + i_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long n = __hip_atomic_load(q_count + sub * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > cap) n = cap;
     if (m.dbg & 1) n = 0;
-    q_items += (unsigned long long)sub * cap;
     const int lane = threadIdx.x & 63;
     for (unsigned long long i0 = (unsigned long long)part * NARROW_T; i0 < n; i0 += (unsigned long long)nparts * NARROW_T) {
         if (threadIdx.x == 0) { pool_n = 0; pool_next = 0; }
@@ -1148,36 +1162,48 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
             const unsigned long long i = i0 + threadIdx.x;
             const bool live = i < n;
             unsigned long long item = 0;
-            if (live) item = __hip_atomic_load(q_items + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i == i_first) item = item_first;
+            else if (live) item = __hip_atomic_load(q_items + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!live) item = 0;
             const long long b = (long long)(item >> 20);
             const int p = (int)(item & 0xFFFFFull);
-            int ra = -1, rb = -1;
-            unsigned ma = 0u, mb = 0u;
-            if (live) {
-                ra = m.vp_canon[2 * p]; rb = m.vp_canon[2 * p + 1];
-                ma = ra >= 0 ? m.rs_mask[ra] : 0u;
-                mb = rb >= 0 ? m.rs_mask[rb] : 0u;
-            }
+            // dead lanes read record 0 / row 0 of this tile (valid memory) and discard it
+            const int4 info = m.vp_info[p];
+            const int ra = live ? info.x : -1, rb = live ? info.y : -1;
+            const unsigned ma = live ? (unsigned)info.z : 0u, mb = live ? (unsigned)info.w : 0u;
             Xf TA, TB;
             xf_from12(m.base_pose, TA);
             TB = TA;
-            // this lane's q row goes to LDS first: all its loads are in flight at once, instead of one global
-            // round trip per joint inside the loop below (the kernel is latency-bound)
+            // this lane's q row goes to LDS first, eight loads in flight at a time, instead of one global round trip
+            // per joint inside the loop below
             double* myq = qstage + threadIdx.x * m.n_q;
-            if (live) {
-                if (es.map != nullptr) {
-                    unsigned e;
-                    const double et = edge_t(es, es.map[b], e);
-                    const double eomt = 1.0 - et;
-                    const double* sp = es.starts + (size_t)e * m.n_q;
-                    const double* gp = es.goals + (size_t)e * m.n_q;
-                    for (int j = 0; j < m.n_q; ++j) { const double a = eomt * sp[j]; const double bb = et * gp[j]; myq[j] = a + bb; }
-                } else {
-                    const double* qrow = q + b * m.n_q;
-                    for (int j = 0; j < m.n_q; ++j) myq[j] = qrow[j];
+            const int nq1 = m.n_q - 1;
+            if (es.map != nullptr) {
+                unsigned e;
+                const double et = edge_t(es, es.map[b], e);
+                const double eomt = 1.0 - et;
+                const double* sp = es.starts + (size_t)e * m.n_q;
+                const double* gp = es.goals + (size_t)e * m.n_q;
+                for (int j0 = 0; j0 < m.n_q; j0 += 4) {
+                    double sv[4], gv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int j = (j0 + u) < nq1 ? (j0 + u) : nq1; sv[u] = sp[j]; gv[u] = gp[j]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (j0 + u <= nq1) { const double a = eomt * sv[u]; const double bb = et * gv[u]; myq[j0 + u] = a + bb; }
+                }
+            } else {
+                const double* qrow = q + b * m.n_q;
+                for (int j0 = 0; j0 < m.n_q; j0 += 8) {
+                    double qv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { const int j = (j0 + u) < nq1 ? (j0 + u) : nq1; qv[u] = qrow[j]; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (j0 + u <= nq1) myq[j0 + u] = qv[u];
                 }
             }
-            for (int k = 0; k < m.n_joints; ++k) {
+            for (int k = 0; k < ((m.dbg & 16) ? 0 : m.n_joints); ++k) {
                 const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
                 if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
                 if (in_a || in_b) {
@@ -1191,13 +1217,14 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
             bool pooled = false;
             Core A, Bc;
             double tc = 0.0;
-            if (live) {
+            if (live && !(m.dbg & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
                 const double* cst = m.vp_cst + 4 * p;
                 int verdict;
-                if (Bc.kind == K_PLANE) verdict = plane_collides(A, Bc, thr, cst[2]) ? 1 : 0;
-                else { tc = (thr + cst[0]) + cst[1]; verdict = cores_collide_pre(A, Bc, tc); }
+                if (m.dbg & 64) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[1][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[1][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; verdict = (acc == 12345.678) ? 1 : 0; }
+                else if (Bc.kind == K_PLANE) verdict = plane_collides(A, Bc, thr, cst[2]) ? 1 : 0;
+                else { tc = BOOL_ONLY ? 0.0 : (thr + cst[0]) + cst[1]; verdict = cores_collide_pre(A, Bc, tc); }
                 if (verdict == 1) mark_hit(b, mask_bits, mask_bytes);
                 pooled = verdict < 0;
             }
@@ -1208,17 +1235,21 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
                 wbase = __builtin_amdgcn_readfirstlane(wbase);
                 if (pooled) {
                     const int slot = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    pool_put(pool, slot, A, Bc, tc, b);
+                    if (POOL_CAP >= NARROW_T || slot < POOL_CAP) pool_put<POOL_CAP>(pool, slot, A, Bc, tc, b);
+                    else {
+                        // pool full (more survivors in this chunk than the pool was sized for): decide in place
+                        const bool hit = (tc == 0.0) ? gjk_intersect(A, Bc) : gjk_collides(A, Bc, tc);
+                        if (hit) mark_hit(b, mask_bits, mask_bytes);
+                    }
                 }
             }
         }
         __syncthreads();
         // ---- phase 2 -----------------------------------------------------------------------------------------------
         {
-            const int np = (m.dbg & 8) ? 0 : pool_n;
+            const int np = (m.dbg & 8) ? 0 : (pool_n < POOL_CAP ? pool_n : POOL_CAP);
             bool have = false;
             Core A, Bc;
-            GjkPred g;
             GjkBool gb;
             double tc = 0.0;
             long long b = 0;
@@ -1226,36 +1257,84 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
 #pragma unroll
             for (int e = 0; e < 3; ++e) { A.c[e] = 0.0; Bc.c[e] = 1.0; A.h[e] = 0.0; Bc.h[e] = 0.0; A.ax[0][e] = A.ax[1][e] = A.ax[2][e] = 0.0; Bc.ax[0][e] = Bc.ax[1][e] = Bc.ax[2][e] = 0.0; }
             A.rad = Bc.rad = A.margin = Bc.margin = A.rho = Bc.rho = 0.0;
-            gjk_pred_init(g, A, Bc);
             gjkb_init(gb, A, Bc);
-            while (true) {
-                // idle lanes take the next pooled items (one LDS atomic per wave and trip)
-                const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
-                if (idle != 0ull) {
-                    int first = 0;
-                    if (lane == 0) first = atomicAdd(&pool_next, __builtin_popcountll(idle));
-                    first = __builtin_amdgcn_readfirstlane(first);
-                    if (!have) {
-                        const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                        if (slot < np) {
-                            pool_get(pool, slot, A, Bc, tc, b);
-                            if (tc == 0.0) gjkb_init(gb, A, Bc); else gjk_pred_init(g, A, Bc);
-                            have = true;
+            if constexpr (BOOL_ONLY) {
+                while (true) {
+                    // idle lanes take the next pooled items (one LDS atomic per wave and trip)
+                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
+                    if (idle != 0ull) {
+                        int first = 0;
+                        if (lane == 0) first = atomicAdd(&pool_next, __builtin_popcountll(idle));
+                        first = __builtin_amdgcn_readfirstlane(first);
+                        if (!have) {
+                            const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                            if (slot < np) {
+                                pool_get<POOL_CAP>(pool, slot, A, Bc, tc, b);
+                                gjkb_init(gb, A, Bc);
+                                have = true;
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+                    if (have) {
+                        const int r = gjkb_step(gb, A, Bc);
+                        if (r != 0) {
+                            if (r == 2) mark_hit(b, mask_bits, mask_bytes);
+                            have = false;
                         }
                     }
                 }
-                if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
-                if (have) {
-                    const int r = (tc == 0.0) ? gjkb_step(gb, A, Bc) : gjk_pred_step(g, A, Bc, tc);
-                    if (r != 0) {
-                        if (r == 2) mark_hit(b, mask_bits, mask_bytes);
-                        have = false;
+            } else {
+                GjkPred g;
+                gjk_pred_init(g, A, Bc);
+                while (true) {
+                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
+                    if (idle != 0ull) {
+                        int first = 0;
+                        if (lane == 0) first = atomicAdd(&pool_next, __builtin_popcountll(idle));
+                        first = __builtin_amdgcn_readfirstlane(first);
+                        if (!have) {
+                            const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                            if (slot < np) {
+                                pool_get<POOL_CAP>(pool, slot, A, Bc, tc, b);
+                                if (tc == 0.0) gjkb_init(gb, A, Bc); else gjk_pred_init(g, A, Bc);
+                                have = true;
+                            }
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+                    if (have) {
+                        const int r = (tc == 0.0) ? gjkb_step(gb, A, Bc) : gjk_pred_step(g, A, Bc, tc);
+                        if (r != 0) {
+                            if (r == 2) mark_hit(b, mask_bits, mask_bytes);
+                            have = false;
+                        }
                     }
                 }
             }
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+                                                      const unsigned long long* __restrict__ q_items,
+                                                      const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    __shared__ double pool[POOL_E * POOL_CAP_BOOL];
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
+    __shared__ int pool_n, pool_next;
+    narrow_body<true, POOL_CAP_BOOL>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, qstage, pool_n, pool_next);
+}
+
+__global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+                                                 const unsigned long long* __restrict__ q_items,
+                                                 const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                 uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    __shared__ double pool[POOL_E * NARROW_T];
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
+    __shared__ int pool_n, pool_next;
+    narrow_body<false, NARROW_T>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, qstage, pool_n, pool_next);
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses
@@ -1784,6 +1863,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
             if (vcls[p] == c) { vorder[cur++] = p; if (c == 0) ++n_plane; if (c == 1) ++n_closed; }
     std::vector<int> vp_tab(4 * (size_t)P), vp_canon(2 * (size_t)P);
     std::vector<double> vp_cst(4 * (size_t)P), ws_center(3 * (size_t)W);
+    bool margins_zero = true;
     for (int i = 0; i < P; ++i) {
         const int p = vorder[i];
         const int ka = kind_of(refA[p]), kb = kind_of(refB[p]);
@@ -1796,6 +1876,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         vp_cst[4 * i] = ca[4]; vp_cst[4 * i + 1] = cb[4];
         vp_cst[4 * i + 2] = host_bound_radius(ka, ca);
         vp_cst[4 * i + 3] = host_bound_radius(kb, cb);
+        if (kb != K_PLANE && (ca[4] != 0.0 || cb[4] != 0.0)) margins_zero = false;
     }
     for (int w = 0; w < W; ++w) { ws_center[3 * w] = ws_core[18 * w]; ws_center[3 * w + 1] = ws_core[18 * w + 1]; ws_center[3 * w + 2] = ws_core[18 * w + 2]; }
     std::vector<unsigned> frame_mask(J > 0 ? J : 1, 0u), rs_mask(S > 0 ? S : 1, 0u);
@@ -1833,7 +1914,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     Blob B;
     nbk_model* M = new nbk_model();
     memset(&M->d, 0, sizeof(M->d));
-    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf; } o;
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi; } o;
     o.jt = B.add(d->joint_type, sizeof(int) * J);
     o.jq = B.add(d->joint_qidx, sizeof(int) * J);
     o.jl = B.add(load.data(), sizeof(int) * J);
@@ -1858,6 +1939,14 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.vk = B.add(vp_cst.data(), sizeof(double) * 4 * P);
     o.wz = B.add(ws_center.data(), sizeof(double) * 3 * W);
     o.rm = B.add(rs_mask.data(), sizeof(unsigned) * S);
+    std::vector<int> vp_info(4 * (size_t)(P > 0 ? P : 1), 0);
+    for (int i = 0; i < P; ++i) {
+        const int ra = vp_canon[2 * i], rb = vp_canon[2 * i + 1];
+        vp_info[4 * i] = ra; vp_info[4 * i + 1] = rb;
+        vp_info[4 * i + 2] = ra >= 0 ? (int)rs_mask[ra] : 0;
+        vp_info[4 * i + 3] = rb >= 0 ? (int)rs_mask[rb] : 0;
+    }
+    o.vi = B.add(vp_info.data(), sizeof(int) * 4 * P);
     std::vector<int> rs_frame_v(S > 0 ? S : 1, -1);
     for (int i = 0; i < S; ++i) rs_frame_v[i] = d->rshape_frame[order[i]];
     o.rf = B.add(rs_frame_v.data(), sizeof(int) * S);
@@ -1899,6 +1988,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.ws_center = reinterpret_cast<const double*>(base + o.wz);
     m.n_plane_pairs = n_plane; m.n_closed_pairs = n_closed;
     m.rs_mask = reinterpret_cast<const unsigned*>(base + o.rm);
+    m.vp_info = reinterpret_cast<const int4*>(base + o.vi);
     m.rs_frame = reinterpret_cast<const int*>(base + o.rf);
     m.bq_tab = reinterpret_cast<const int*>(base + o.bt);
     for (int c = 0; c < 4; ++c) { m.bq_count[c] = 0; }
@@ -1909,6 +1999,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->ews = nullptr; M->ews_bytes = 0;
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
+    M->margins_zero = margins_zero;
     (void)hipGetDevice(&M->device);
     *out = M;
     return NBK_OK;
@@ -2027,8 +2118,11 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         else
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_narrow, dim3(NSUB * 32), dim3(NARROW_T), sizeof(double) * NARROW_T * (size_t)m->n_q, st, m->d, es_tile, q ? q + b0 * m->n_q : nullptr, threshold, items, count, cap_sub,
-                           mask_bits ? mask_bits + b0 / 64 : nullptr, mask_bytes ? mask_bytes + b0 : nullptr);
+        const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q;
+        if (threshold == 0.0 && m->margins_zero)
+            hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * 32), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+        else
+            hipLaunchKernelGGL(k_narrow, dim3(NSUB * 32), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         NBK_HIP(hipGetLastError());
     }
     return NBK_OK;

@@ -1,0 +1,111 @@
+"""Reduce rocprofv3 PMC passes to the per-launch figures bench.py and DESIGN.md quote.
+
+    python tools/reduce_pmc.py --tag r01_f --batch 1000000
+
+reads  profiles/<tag>_pmc_fetch_size_counter_collection.csv   (rocprofv3 --kernel-trace --pmc FETCH_SIZE)
+       profiles/<tag>_pmc_write_size_counter_collection.csv   (... --pmc WRITE_SIZE)
+       profiles/<tag>_pmc_sq_counter_collection.csv           (... --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU
+                                                                     SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU)
+       profiles/<tag>_pmc_clk_counter_collection.csv          (... --pmc GRBM_GUI_ACTIVE; optional)
+writes profiles/<tag>_traffic.json
+
+Units and corrections (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are KiB per
+dispatch; on gfx950 wide coalesced reads are reported at 1/2, so fetch bytes = 2 * FETCH_SIZE * 1024.  Every
+figure is the mean over the dispatches of that kernel in the run (all at the same batch).
+"""
+import argparse
+import csv
+import json
+import os
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SIMD = 256 * 4
+CLOCK_HZ = 2.4e9
+VALU_F64_CYCLES = 4          # one wave64 float64 VALU instruction occupies its SIMD for 4 cycles (16 lanes/cycle)
+
+KERNELS = {"k_broad_reg": "nbk::k_broad_reg", "k_broad": "nbk::k_broad(", "k_narrow": "nbk::k_narrow",
+           "k_fk": "nbk::k_fk", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
+
+
+def short(name):
+    for k, pat in KERNELS.items():
+        if pat in name:
+            return k
+    return None
+
+
+def read(path):
+    """{kernel: {counter: [value per dispatch]}}, {kernel: [duration ns]}, {kernel: grid}"""
+    vals = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(dict)
+    grid = {}
+    if not os.path.exists(path):
+        return None, None, None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            if k is None:
+                continue
+            vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[k][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            grid[k] = int(r["Grid_Size"])
+    return vals, {k: list(v.values()) for k, v in dur.items()}, grid
+
+
+def mean(x):
+    return sum(x) / len(x)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--batch", type=int, default=1_000_000)
+    a = ap.parse_args()
+    p = lambda s: os.path.join(ROOT, "profiles", f"{a.tag}_pmc_{s}_counter_collection.csv")
+    fetch, _, _ = read(p("fetch_size"))
+    write, _, _ = read(p("write_size"))
+    sq, sq_dur, grid = read(p("sq"))
+    clk, clk_dur, _ = read(p("clk"))
+    out = {"command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+           "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (mean over dispatches); gfx950 correction per "
+                    "MI355X_MICROARCH.md: wide coalesced reads report 1/2 -> fetch_bytes = 2*FETCH_SIZE*1024",
+           "kernels": {}, "batch": a.batch}
+    for k in sorted(set(fetch or {}) & set(write or {})):
+        fk, wk = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"])
+        out["kernels"][k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": 2 * fk * 1024,
+                             "write_bytes": wk * 1024, "hbm_bytes_corrected": 2 * fk * 1024 + wk * 1024}
+    step = [k for k in ("k_broad_reg", "k_broad", "k_narrow", "k_validity") if k in out["kernels"]]
+    out["validity_step_kernels"] = step
+    out["validity_step_hbm_bytes"] = sum(out["kernels"][k]["hbm_bytes_corrected"] for k in step)
+    if sq:
+        out["sq"] = {}
+        for k, c in sq.items():
+            waves = (grid[k] + 63) // 64
+            insts = mean(c["SQ_INSTS_VALU"])
+            d = {"waves": waves, "valu_insts_per_wave": insts / waves,
+                 "lane_utilisation": mean(c["SQ_THREAD_CYCLES_VALU"]) / (insts * 64),
+                 "valu_fraction_of_wave_lifetime": insts / mean(c["SQ_WAVE_CYCLES"]),
+                 "wait_fraction_of_wave_lifetime": mean(c["SQ_WAIT_INST_ANY"]) / mean(c["SQ_WAVE_CYCLES"]),
+                 "salu_insts_per_wave": mean(c["SQ_INSTS_SALU"]) / waves,
+                 "lds_insts_per_wave": mean(c["SQ_INSTS_LDS"]) / waves,
+                 "kernel_us_under_pmc": mean(sq_dur[k]) / 1e3}
+            # SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY count quad-cycles.  Direct estimates over the launch at the nominal
+            # 2.4 GHz engine clock: VALU instructions x 4 cycles (float64 wave64) over the SIMD-cycles available.
+            cyc = mean(sq_dur[k]) * 1e-9 * CLOCK_HZ
+            d["simd_valu_issue_utilisation"] = insts * VALU_F64_CYCLES / (N_SIMD * cyc)
+            d["resident_waves_per_simd"] = mean(c["SQ_WAVE_CYCLES"]) * 4 / (N_SIMD * cyc)
+            if clk and k in clk and "GRBM_GUI_ACTIVE" in clk[k]:
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs and includes the dispatch overhead around short kernels:
+                # an upper bound on the clock, recorded as a sanity check of the nominal figure
+                d["clock_ghz_upper_bound"] = mean(clk[k]["GRBM_GUI_ACTIVE"]) / 8 / mean(clk_dur[k])
+            out["sq"][k] = d
+        out["sq_source"] = f"profiles/{a.tag}_pmc_sq_counter_collection.csv (+ _clk_ for GRBM_GUI_ACTIVE)"
+    dst = os.path.join(ROOT, "profiles", f"{a.tag}_traffic.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
