@@ -144,6 +144,18 @@ int32_t nbk_pair_distances_batch(const nbk_model *m, const double *q, int64_t B,
                                  double *witness, void *stream);
 
 /*
+ * Batched Arm.jacobian_proximity (numbotics/robots/arm.py:620-632) over every allowed pair: besides dist [B][P] and
+ * witness [B][P][9] (as above), jrows [B][P][n_q] with
+ *   jrows[b][p] = n . Jv_subject(q_b; position_on_subject) - n . Jv_target(q_b; position_on_target),
+ * n = normal_target_to_subject, Jv = the linear rows of Arm.jacobian(..., global_pose=trans_mat(pos=point))
+ * (numbotics/robots/helpers.py:117-187); the target term is dropped for world targets (arm.py:628).
+ * These are the gradient rows of the pair distances that IrisSolver's counter-example search consumes
+ * (numbotics/planning/safe_sets.py:86-121).
+ */
+int32_t nbk_proximity_jacobian_batch(const nbk_model *m, const double *q, int64_t B, double *dist,
+                                     double *witness, double *jrows, void *stream);
+
+/*
  * Batched DiscreteConnector.connect / steer (numbotics/planning/sampling_based/connectors.py:57-100)
  * with the default linear trajectory (numbotics/planning/trajectories.py:6-22) and
  * validity_checker = not in_collision(q, threshold).

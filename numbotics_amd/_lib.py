@@ -20,7 +20,7 @@ SYMBOLS = [
     "nbk_model_create", "nbk_model_destroy", "nbk_model_num_pairs",
     "nbk_fk_batch", "nbk_jacobian_batch", "nbk_validity_batch", "nbk_validity_workspace_bytes",
     "nbk_validity_batch_ws", "nbk_closest_batch",
-    "nbk_pair_distances_batch", "nbk_edge_validity_batch", "nbk_selftest_math",
+    "nbk_pair_distances_batch", "nbk_proximity_jacobian_batch", "nbk_edge_validity_batch", "nbk_selftest_math",
     "nbk_fk_batch_host", "nbk_validity_batch_host",
 ]
 
@@ -73,6 +73,7 @@ def load():
     lib.nbk_validity_batch_ws.argtypes = [vp, vp, i64, f64, vp, vp, vp, i64, vp]
     lib.nbk_closest_batch.argtypes = [vp, vp, i64, vp, vp, vp]
     lib.nbk_pair_distances_batch.argtypes = [vp, vp, i64, vp, vp, vp]
+    lib.nbk_proximity_jacobian_batch.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.nbk_edge_validity_batch.argtypes = [vp, vp, vp, vp, i64, f64, f64, i32, f64, vp, vp, vp, vp]
     lib.nbk_selftest_math.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
     lib.nbk_fk_batch_host.argtypes = [vp, vp, i64, vp, i32, vp, vp]

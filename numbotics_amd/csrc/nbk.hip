@@ -335,7 +335,8 @@ __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const
 
 // ---- collision: sweep the tree, park robot cores in LDS ---------------------------------------------
 // LDS rows of 64 doubles: [n_q q rows][shape_rows][frame_slots * 12]
-NBK_DEV void sweep_and_park(const DevModel& m, double* lds_q, double* lds_s, double* lds_fr, int lane) {
+// lds_jz (optional): [J][6] rows -- world axis w_k = R_k a_k and origin o_k of every joint, for Jacobian rows
+NBK_DEV void sweep_and_park(const DevModel& m, double* lds_q, double* lds_s, double* lds_fr, int lane, double* lds_jz = nullptr) {
     Xf base;
     xf_from12(m.base_pose, base);
     Xf T = base;
@@ -353,6 +354,14 @@ NBK_DEV void sweep_and_park(const DevModel& m, double* lds_q, double* lds_s, dou
             }
             const double qk = lds_q[m.joint_qidx[k] * WAVE + lane];
             joint_apply(m, k, P, qk, T);
+            if (lds_jz != nullptr) {
+                const double* a = m.joint_axis + 3 * k;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    lds_jz[(6 * k + r) * WAVE + lane] = NBK_FMA(T.R[3 * r + 2], a[2], NBK_FMA(T.R[3 * r + 1], a[1], T.R[3 * r] * a[0]));
+                    lds_jz[(6 * k + 3 + r) * WAVE + lane] = T.t[r];
+                }
+            }
             const int sv = m.joint_save[k];
             if (sv >= 0) {
 #pragma unroll
@@ -1337,11 +1346,14 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
     narrow_body<false, NARROW_T>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, qstage, pool_n, pool_next);
 }
 
-// MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses
+// MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses;
+// MODE 3: distances + witnesses + proximity-Jacobian rows (Arm.jacobian_proximity, arm.py:620-632):
+//         row[col(k)] = n . Jv_subject,k(p_s) - n . Jv_target,k(p_t) over the joints k above each shape, with
+//         Jv_k(r) = w_k x (r - o_k) (revolute) or w_k (prismatic); world targets contribute nothing.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __restrict__ q, int64_t B,
                                                    double* __restrict__ out_d, int32_t* __restrict__ out_i,
-                                                   double* __restrict__ out_w) {
+                                                   double* __restrict__ out_w, double* __restrict__ out_j = nullptr) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
@@ -1351,14 +1363,15 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
     const int64_t b = base + lane;
     const bool active = b < B;
-    sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
+    double* lds_jz = (MODE == 3) ? lds_fr + WAVE * 12 * m.frame_slots : nullptr;
+    sweep_and_park(m, lds_q, lds_s, lds_fr, lane, lds_jz);
     double best = NBK_INF;
     int bi = -1;
     for (int p = 0; p < m.n_pairs; ++p) {
         Core A, Bc;
         load_pair(m, lds_s, p, lane, A, Bc);
         double wit[9];
-        const double d = cores_distance<MODE == 2>(A, Bc, wit);
+        const double d = cores_distance<(MODE >= 2)>(A, Bc, wit);
         if constexpr (MODE == 0) {
             // pairs are visited in device order; ties resolve to the smallest USER index like the oracle
             const int u = m.pair_user[p];
@@ -1367,9 +1380,33 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
             if (active) {
                 const int64_t o = b * m.n_pairs + m.pair_user[p];
                 out_d[o] = d;
-                if constexpr (MODE == 2) {
+                if constexpr (MODE >= 2) {
 #pragma unroll
                     for (int e = 0; e < 9; ++e) out_w[o * 9 + e] = wit[e];
+                }
+                if constexpr (MODE == 3) {
+                    double* row = out_j + o * m.n_q;
+                    for (int c = 0; c < m.n_q; ++c) row[c] = 0.0;
+                    const int sa = m.pair_a[p], sb = m.pair_b[p];
+                    const unsigned ma = m.rs_mask[sa];
+                    const unsigned mb = sb < m.n_rshapes ? m.rs_mask[sb] : 0u;
+                    for (int k = 0; k < m.n_joints; ++k) {
+                        const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
+                        if (!in_a && !in_b) continue;
+                        const double w[3] = {lds_jz[(6 * k) * WAVE + lane], lds_jz[(6 * k + 1) * WAVE + lane], lds_jz[(6 * k + 2) * WAVE + lane]};
+                        const double o3[3] = {lds_jz[(6 * k + 3) * WAVE + lane], lds_jz[(6 * k + 4) * WAVE + lane], lds_jz[(6 * k + 5) * WAVE + lane]};
+                        const bool rev = m.joint_type[k] == NBK_REVOLUTE;
+                        double va = 0.0, vb = 0.0;
+                        if (in_a) {
+                            if (rev) { double dd[3], v[3]; sub3(wit, o3, dd); cross3(w, dd, v); va = dot3(wit + 6, v); }
+                            else va = dot3(wit + 6, w);
+                        }
+                        if (in_b) {
+                            if (rev) { double dd[3], v[3]; sub3(wit + 3, o3, dd); cross3(w, dd, v); vb = dot3(wit + 6, v); }
+                            else vb = dot3(wit + 6, w);
+                        }
+                        row[m.joint_qidx[k]] = va - vb;
+                    }
                 }
             }
         }
@@ -2195,6 +2232,18 @@ int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B,
     else
         hipLaunchKernelGGL(k_distances<1>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
                            (int32_t*)nullptr, (double*)nullptr);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_proximity_jacobian_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, double* jrows,
+                                     void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr || witness == nullptr || jrows == nullptr))) return NBK_ERR_INVALID;
+    if (B == 0 || m->n_pairs == 0) return NBK_OK;
+    const size_t lds = collide_lds(m) + sizeof(double) * WAVE * 6 * (size_t)m->n_joints;
+    if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_distances<3>, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, q, B, dist, (int32_t*)nullptr,
+                       witness, jrows);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }

@@ -192,6 +192,17 @@ class DeviceModel:
                    "nbk_pair_distances_batch")
         return (qs.out(d), qs.out(w)) if witness else qs.out(d)
 
+    def proximity_jacobian(self, q):
+        """(B,P) signed distances, (B,P,9) witnesses and (B,P,n_q) proximity-Jacobian rows of every allowed pair."""
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        d = torch.empty((qs.B, self.n_pairs), dtype=torch.float64, device=qs.device)
+        w = torch.empty((qs.B, self.n_pairs, 9), dtype=torch.float64, device=qs.device)
+        j = torch.empty((qs.B, self.n_pairs, self.n_q), dtype=torch.float64, device=qs.device)
+        _lib.check(self._lib.nbk_proximity_jacobian_batch(self._h, qs.t.data_ptr(), qs.B, d.data_ptr(), w.data_ptr(),
+                                                          j.data_ptr(), self._stream()), "nbk_proximity_jacobian_batch")
+        return qs.out(d), qs.out(w), qs.out(j)
+
     def edge_validity(self, starts, goals, resolution, max_distance, mode="connect", threshold=0.0, dist=None):
         torch = _require_gpu()
         s = _Staged(starts, self.n_q)

@@ -1,7 +1,7 @@
 """The data-parallel inner steps of the reference's IRIS solver on the device
 (reference: numbotics/planning/safe_sets.py:124-134,164-201).
 
-Only the two collision-bound steps are provided; the convex programmes around them (hit-and-run sampling,
+Only the collision-bound steps are provided; the convex programmes around them (hit-and-run sampling,
 cvxpy/MOSEK ellipsoid, SLSQP) are out of scope.
 
 * ``collision_mask(arm, points, tol)`` = ``[subject.in_collision(q, tol) for q in points]``, which upstream maps
@@ -9,6 +9,9 @@ cvxpy/MOSEK ellipsoid, SLSQP) are out of scope.
 * ``counter_example_bisection(arm, centre, points, num_bisections, tol)`` = ``counter_ex_search_bisection`` for
   every colliding sample at once (safe_sets.py:124-134): ``num_bisections`` launches on shrinking intervals
   instead of ``M * num_bisections`` single-configuration PyBullet queries.
+* ``distance_and_gradient(arm, points, link, obj)`` = the constraint value and Jacobian that
+  ``counter_ex_search_nlp`` hands to SLSQP (safe_sets.py:86-121: ``distance_to(x, link, obj)[0].distance`` and
+  ``jacobian_proximity(x, link=link, obj=obj)``), for M points in one launch.
 """
 import numpy as np
 
@@ -32,3 +35,20 @@ def counter_example_bisection(arm, centre, points, num_bisections: int = 15, col
         hi[hit] = mid[hit]
         lo[~hit] = mid[~hit]
     return hi
+
+
+def distance_and_gradient(arm, points, link, obj):
+    """(M, dof) -> signed distance (M,) of the body pair (link, obj) and its gradient rows (M, dof).
+
+    A body pair of compound links has several primitive pairs: the closest one is reported per point (for
+    single-primitive links this is upstream's ``[0]``)."""
+    sm, _ = arm._scene_device()
+    if not arm._has(arm.collision_pairs(), link, obj):
+        raise ValueError(f"Collision pair ({link.name}, {obj.name}) not valid")
+    sel = arm._pair_selection(sm, obj, link)
+    points = np.asarray(points, dtype=np.float64).reshape(-1, arm.dof)
+    dist, _, rows = arm.proximity_jacobians(points)
+    dist, rows = np.asarray(dist)[:, sel], np.asarray(rows)[:, sel]
+    k = np.argmin(dist, axis=1)
+    i = np.arange(points.shape[0])
+    return dist[i, k], rows[i, k]

@@ -392,25 +392,50 @@ class Arm(Robot):
         sm, dev = self._scene_device()
         return dev.closest(q.reshape(-1, self.dof))
 
-    def distance_to(self, q, obj, link=None):
+    def _pair_selection(self, sm, obj, link):
+        """Indices (into the scene's primitive pair list) of the proximities ``distance_to(q, obj, link)`` returns."""
         pairs = self.collision_pairs()
-        prox = [p for p in self.collisions(q) if p.target == obj or (isinstance(obj, Chain) and self._in_chain(p.target)
-                                                                      and obj == self._chain)]
-        if link is None:
-            return [p for p in prox if self._has(pairs, p.subject, p.target)]
-        if not self._has(pairs, link, obj):
+        sel = []
+        for p in range(sm.n_pairs):
+            subj, targ = sm.pair_members(p)
+            if not (targ == obj or (isinstance(obj, Chain) and self._in_chain(targ) and obj == self._chain)):
+                continue
+            if link is None:
+                if self._has(pairs, subj, targ):
+                    sel.append(p)
+            elif subj == link:
+                sel.append(p)
+        return sel
+
+    def distance_to(self, q, obj, link=None):
+        if link is not None and not self._has(self.collision_pairs(), link, obj):
             raise ValueError(f"Collision pair ({link.name}, {obj.name}) not valid")
-        return [p for p in prox if p.subject == link]
+        sm, _ = self._scene_device()
+        prox = self.collisions(q)
+        return [prox[p] for p in self._pair_selection(sm, obj, link)]
+
+    def proximity_jacobians(self, q):
+        """Batched ``collisions`` + ``jacobian_proximity`` over every allowed primitive pair (additive):
+        ``(..., dof)`` -> signed distances ``(B, P)``, witnesses ``(B, P, 9)`` (point on subject, point on target,
+        normal target->subject) and rows ``(B, P, dof)`` with row = n . Jv_subject(p_s) - n . Jv_target(p_t)
+        (arm.py:620-632), one launch."""
+        sm, dev = self._scene_device()
+        return dev.proximity_jacobian(q.reshape(-1, self.dof))
 
     def jacobian_proximity(self, q, obj, link=None):
-        from numbotics_amd.math import trans_mat
-        proximities = self.distance_to(q, obj, link)
-        J = np.zeros((len(proximities), self.dof))
-        for i, p in enumerate(proximities):
-            n = p.normal_target_to_subject
-            J[i] = n @ self.jacobian(q, p.subject._name, global_pose=trans_mat(pos=p.position_on_subject))[:3]
-            if self._in_chain(p.target):
-                J[i] -= n @ self.jacobian(q, p.target._name, global_pose=trans_mat(pos=p.position_on_target))[:3]
+        """As upstream (arm.py:620-632): one row per proximity of ``distance_to(q, obj, link)``, a 1-D row when
+        there is exactly one."""
+        if tuple(q.shape) != (self.dof,):
+            raise ValueError(f"q must be a 1D array with {self.dof} elements")
+        if link is not None and not self._has(self.collision_pairs(), link, obj):
+            raise ValueError(f"Collision pair ({link.name}, {obj.name}) not valid")
+        sm, dev = self._scene_device()
+        sel = self._pair_selection(sm, obj, link)
+        qn = q.detach().cpu().numpy() if _is_tensor(q) else np.asarray(q, dtype=np.float64)
+        if not sel:
+            return np.zeros((0, self.dof))
+        _, _, rows = dev.proximity_jacobian(qn.reshape(1, -1))
+        J = np.ascontiguousarray(rows[0][sel])
         if J.shape[0] == 1:
             return J[0]
         return J

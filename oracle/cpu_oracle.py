@@ -137,6 +137,15 @@ class Oracle:
         lib().orc_pair_distances(C.byref(self._m), _p(q), C.c_int64(B), _p(dist), None if wit is None else _p(wit))
         return (dist, wit) if witness else dist
 
+    def proximity_jacobian(self, q):
+        q = _f64(q, (-1, self.n_q))
+        B = q.shape[0]
+        dist = np.empty((B, self.n_pairs))
+        wit = np.empty((B, self.n_pairs, 9))
+        rows = np.empty((B, self.n_pairs, self.n_q))
+        lib().orc_proximity_jacobian(C.byref(self._m), _p(q), C.c_int64(B), _p(dist), _p(wit), _p(rows))
+        return dist, wit, rows
+
     def closest(self, q):
         q = _f64(q, (-1, self.n_q))
         B = q.shape[0]

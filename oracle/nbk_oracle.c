@@ -1016,6 +1016,53 @@ int orc_pair_distances(const orc_model *m, const double *q, int64_t B, double *d
     return 0;
 }
 
+/* bit k set = joint k lies on the path from the base to moving frame f */
+static unsigned frame_mask(const orc_model *m, int f) {
+    unsigned mk = 0u;
+    while (f >= 0) { mk |= 1u << f; f = m->joint_parent[f]; }
+    return mk;
+}
+
+int orc_proximity_jacobian(const orc_model *m, const double *q, int64_t B, double *dist, double *witness, double *jrows) {
+    core_t *wc = build_world_cores(m);
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
+    core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
+    const int nq = m->n_q;
+    for (int64_t b = 0; b < B; ++b) {
+        robot_cores(m, q + b * nq, frames, rc);
+        for (int p = 0; p < m->n_pairs; ++p) {
+            double *wit = witness + (b * m->n_pairs + p) * 9;
+            double *row = jrows + (b * m->n_pairs + p) * nq;
+            dist[b * m->n_pairs + p] = pair_eval(m, rc, wc, p, wit);
+            for (int c = 0; c < nq; ++c) row[c] = 0.0;
+            const int sa = m->pair_a[p], sb = m->pair_b[p];
+            const unsigned ma = frame_mask(m, m->rshape_frame[sa]);
+            const unsigned mb = sb < m->n_rshapes ? frame_mask(m, m->rshape_frame[sb]) : 0u;
+            for (int k = 0; k < m->n_joints; ++k) {
+                const int in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
+                if (!in_a && !in_b) continue;
+                const double *a = m->joint_axis + 3 * k;
+                const xf_t *F = &frames[k];
+                double w[3];
+                for (int r = 0; r < 3; ++r) w[r] = FMA(F->R[3 * r + 2], a[2], FMA(F->R[3 * r + 1], a[1], F->R[3 * r] * a[0]));
+                const int rev = m->joint_type[k] == ORC_REVOLUTE;
+                double va = 0.0, vb = 0.0;
+                if (in_a) {
+                    if (rev) { double dd[3], v[3]; sub3(wit, F->t, dd); cross3(w, dd, v); va = dot3(wit + 6, v); }
+                    else va = dot3(wit + 6, w);
+                }
+                if (in_b) {
+                    if (rev) { double dd[3], v[3]; sub3(wit + 3, F->t, dd); cross3(w, dd, v); vb = dot3(wit + 6, v); }
+                    else vb = dot3(wit + 6, w);
+                }
+                row[m->joint_qidx[k]] = va - vb;
+            }
+        }
+    }
+    free(wc); free(frames); free(rc);
+    return 0;
+}
+
 int orc_closest(const orc_model *m, const double *q, int64_t B, double *min_dist, int32_t *argmin) {
     core_t *wc = build_world_cores(m);
     xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));

@@ -74,6 +74,10 @@ int orc_jacobian(const orc_model *m, const double *q, int64_t B, const int32_t *
 /* signed distance of every allowed pair: dist [B][P]; witness (optional) [B][P][9] =
  * point on A, point on B, unit normal from B to A. */
 int orc_pair_distances(const orc_model *m, const double *q, int64_t B, double *dist, double *witness);
+/* Arm.jacobian_proximity (numbotics/robots/arm.py:620-632) for every allowed pair: dist, witness as above and
+ * jrows [B][P][n_q] = n . Jv_subject(point on A) - n . Jv_target(point on B) (world targets: no second term), Jv =
+ * linear rows of orc_jacobian mode 2 (numbotics/robots/helpers.py:117-187). */
+int orc_proximity_jacobian(const orc_model *m, const double *q, int64_t B, double *dist, double *witness, double *jrows);
 /* min over pairs and its index (first minimum).  P == 0 -> +inf / -1. */
 int orc_closest(const orc_model *m, const double *q, int64_t B, double *min_dist, int32_t *argmin);
 /* mask[b] = (min_p dist < threshold) ? 1 : 0 ; nthreads <= 1 runs serially */

@@ -388,6 +388,71 @@ def test_iris_inner_steps(fresh_world, torch_cuda):
     assert np.asarray(arm.in_collision(hi, 1e-6)).all()          # the returned ends are still colliding
 
 
+def _tree_scene():
+    from numbotics_amd.physics import GraphChain, Cube, Sphere, Capsule
+    from numbotics_amd.robots import Arm
+    chain = GraphChain.from_urdf(TREE_URDF)
+    arm = Arm(chain)
+    obs = [Cube(0.0, 0.08, position=np.array([0.35, 0.0, 0.55])), Sphere(0.0, 0.05, position=np.array([0.2, 0.2, 0.4])),
+           Capsule(0.0, 0.03, 0.3, position=np.array([-0.2, 0.1, 0.6]))]
+    return arm, chain, obs
+
+
+@pytest.mark.parametrize("scene", ["c2", "c3", "tree"])
+def test_proximity_jacobian_rows(fresh_world, scene, torch_cuda):
+    """batched Proximity records + jacobian_proximity rows (arm.py:607-632) in one launch,
+    bit-exact against the oracle; the scalar API equals the composition the reference writes down."""
+    import ctypes as C
+    from numbotics_amd.math import trans_mat
+    from numbotics_amd.planning.safe_sets import distance_and_gradient
+    arm, chain, obs = _tree_scene() if scene == "tree" else build_scene(scene)
+    sm = arm.scene_model()
+    orc = Oracle(sm)
+    M = 10071 if scene == "c2" else 1500                       # config 5's sample count on the benchmark scene
+    q = sample_q(chain, M, seed=41)
+    d, w, rows = arm.proximity_jacobians(q)
+    dr, wr, rr = orc.proximity_jacobian(q)
+    assert_bitwise(d, dr, "proximity distances")
+    assert_bitwise(w, wr, "proximity witnesses")
+    assert_bitwise(rows, rr, "proximity jacobian rows")
+    assert rows.shape == (M, sm.n_pairs, chain.dof) and np.abs(rows).max() > 0.1
+    # torch in -> torch out, same bits
+    qt = torch_cuda.from_numpy(q[:256]).cuda()
+    dt, wt, rt = arm.proximity_jacobians(qt)
+    assert rt.is_cuda and np.array_equal(rt.cpu().numpy(), rows[:256])
+    # scalar API of the reference: rows for one obstacle / for the chain itself, built from the device Jacobian
+    target = obs[0]
+    J = np.atleast_2d(arm.jacobian_proximity(q[0], target))
+    prox = arm.distance_to(q[0], target)
+    assert J.shape == (len(prox), chain.dof) and len(prox) >= 1
+    for i, p in enumerate(prox):
+        n = p.normal_target_to_subject
+        ref = n @ arm.jacobian(q[0], p.subject._name, global_pose=trans_mat(pos=p.position_on_subject))[:3]
+        assert np.abs(J[i] - ref).max() < 1e-12
+    Js = np.atleast_2d(arm.jacobian_proximity(q[1], chain))
+    prox = arm.distance_to(q[1], chain)
+    assert Js.shape[0] == len(prox) >= 1
+    for i, p in enumerate(prox[:6]):
+        n = p.normal_target_to_subject
+        ref = n @ arm.jacobian(q[1], p.subject._name, global_pose=trans_mat(pos=p.position_on_subject))[:3] \
+            - n @ arm.jacobian(q[1], p.target._name, global_pose=trans_mat(pos=p.position_on_target))[:3]
+        assert np.abs(Js[i] - ref).max() < 1e-12
+    # the NLP constraint and its Jacobian for a body pair (safe_sets.py:86-121), batched
+    link = arm.distance_to(q[0], target)[0].subject
+    dist, grad = distance_and_gradient(arm, q[:64], link, target)
+    sel = arm._pair_selection(sm, target, link)
+    assert np.array_equal(dist, dr[:64][:, sel].min(axis=1))
+    k = dr[:64][:, sel].argmin(axis=1)
+    assert np.array_equal(grad, rr[:64][:, sel][np.arange(64), k])
+    # C boundary: status codes
+    from numbotics_amd import _lib
+    lib = _lib.load()
+    _, dev = arm._scene_device()
+    st = C.c_void_p(torch_cuda.cuda.current_stream().cuda_stream)
+    assert lib.nbk_proximity_jacobian_batch(dev._h, qt.data_ptr(), 256, dt.data_ptr(), wt.data_ptr(), None, st) == -1
+    assert lib.nbk_proximity_jacobian_batch(dev._h, qt.data_ptr(), 0, None, None, None, st) == 0
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""

@@ -17,3 +17,6 @@ def t(fn, n=5):
 print('closest ms %.3f for %d -> %.3e cfg/s'%((ms:=t(lambda: dev.closest(q))), B, B/ms*1e3))
 print('pair_distances ms %.3f -> %.3e cfg/s'%((ms:=t(lambda: dev.pair_distances(q))), B/ms*1e3))
 print('pair_distances+witness ms %.3f -> %.3e cfg/s'%((ms:=t(lambda: dev.pair_distances(q, witness=True))), B/ms*1e3))
+print('proximity jacobian rows ms %.3f -> %.3e cfg/s'%((ms:=t(lambda: dev.proximity_jacobian(q))), B/ms*1e3))
+q5 = q[:10071]
+print('config 5 (10071 samples): proximity records + rows ms %.3f; mask ms %.3f'%(t(lambda: dev.proximity_jacobian(q5), 20), t(lambda: dev.validity(q5, 1e-6), 20)))
