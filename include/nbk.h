@@ -107,6 +107,21 @@ int32_t nbk_jacobian_batch(const nbk_model *m, const double *q, int64_t B, const
                            double *J_out, void *stream);
 
 /*
+ * Batched Arm.inverse_kinematics (numbotics/robots/arm.py:464-552): damped least squares
+ *   q <- q + J^T (J J^T + lambda I)^-1 diff,  diff = [p* - p ; vee(0.5 (R - R^T))], R = R* R_ee^T
+ * (numbotics/math/spatial.py:207-212), lambda_0 = 0.1, x1.2 / failures+1 when |diff| grew, x0.5 / failures = 0 otherwise;
+ * an element iterates while |diff| > tol and failures < max_failures, at most max_iter times.
+ *   pose [B][16] target poses, q0 [B][n_q] starts; path / local as for nbk_fk_batch (host);
+ *   limits (host, optional) [n_q][2]: clip q to [lower, upper] after every step (use_limits=True);
+ *   q_out [B][n_q]; success [B] uint8 = |diff| < tol; diff_norm (optional) [B]; iters (optional) [B] int32 steps taken.
+ * The 6x6 damped system is solved by an unpivoted Cholesky (the reference calls LAPACK LU): equal to rounding.
+ */
+int32_t nbk_ik_batch(const nbk_model *m, const double *pose, const double *q0, int64_t B, const int32_t *path,
+                     int32_t path_len, const double *local, const double *limits, double tol, int32_t max_iter,
+                     int32_t max_failures, double *q_out, uint8_t *success, double *diff_norm, int32_t *iters,
+                     void *stream);
+
+/*
  * Batched Arm.in_collision (numbotics/robots/arm.py:603-604): bit b of mask_bits / mask_bytes[b] is 1
  * iff min over the allowed pairs of the signed distance is < threshold (strict).  Replaces the
  * per-configuration PyBullet round trip Arm.collisions -> Chain.distance_to -> getClosestPoints

@@ -333,6 +333,179 @@ __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const
     }
 }
 
+
+// ---- batched Levenberg-Marquardt inverse kinematics (Arm.inverse_kinematics, robots/arm.py:464-552) ----------
+// One problem per lane, the whole iteration in one launch:
+//   q <- q + J^T (J J^T + lambda I)^-1 diff,  optional clip to the joint limits,  FK,  diff = [p* - p ; vee(0.5 (R - R^T))]
+//   with R = R* R_ee^T (math/spatial.py:207-212);  lambda *= 1.2 and failures += 1 when |diff| grew, else
+//   lambda *= 0.5 and failures = 0;  an element runs while |diff| > tol and failures < max_failures.
+// One sweep of the path gives both the pose (for this iteration's diff) and the Jacobian (for the next step).  The
+// 6x6 system is symmetric positive definite (lambda > 0): an unpivoted Cholesky in registers, where the reference
+// calls LAPACK's LU (np.linalg.solve) -- equal to rounding, not bit for bit; a non-positive pivot stops the element.
+// LDS rows of 64 doubles: [n_q q][6 n_q J][6 path_len joint axes and origins].
+struct IkArg { double tol; int max_iter; int max_failures; int use_limits; double lo[NBK_MAX_DOF]; double hi[NBK_MAX_DOF]; };
+
+NBK_DEV void ik_sweep(const DevModel& m, const PathArg& path, const double* lds_q, double* lds_J, double* lds_jz, int lane, Xf& E) {
+    Xf T;
+    xf_from12(m.base_pose, T);
+    for (int i = 0; i < path.len; ++i) {
+        const int k = path.idx[i];
+        Xf nxt;
+        joint_apply(m, k, T, lds_q[m.joint_qidx[k] * WAVE + lane], nxt);
+        T = nxt;
+        const double* a = m.joint_axis + 3 * k;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            lds_jz[(6 * i + r) * WAVE + lane] = NBK_FMA(T.R[3 * r + 2], a[2], NBK_FMA(T.R[3 * r + 1], a[1], T.R[3 * r] * a[0]));
+            lds_jz[(6 * i + 3 + r) * WAVE + lane] = T.t[r];
+        }
+    }
+    Xf loc;
+    xf_from12(path.local, loc);
+    xf_mul(T, loc.R, loc.t, E);
+    const int nq = m.n_q;
+    for (int i = 0; i < path.len; ++i) {
+        const int k = path.idx[i];
+        const int col = m.joint_qidx[k];
+        const double w[3] = {lds_jz[(6 * i) * WAVE + lane], lds_jz[(6 * i + 1) * WAVE + lane], lds_jz[(6 * i + 2) * WAVE + lane]};
+        if (m.joint_type[k] == NBK_REVOLUTE) {
+            const double o[3] = {lds_jz[(6 * i + 3) * WAVE + lane], lds_jz[(6 * i + 4) * WAVE + lane], lds_jz[(6 * i + 5) * WAVE + lane]};
+            double d[3], v[3];
+            sub3(E.t, o, d);
+            cross3(w, d, v);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { lds_J[(r * nq + col) * WAVE + lane] = v[r]; lds_J[((3 + r) * nq + col) * WAVE + lane] = w[r]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { lds_J[(r * nq + col) * WAVE + lane] = w[r]; lds_J[((3 + r) * nq + col) * WAVE + lane] = 0.0; }
+        }
+    }
+}
+
+NBK_DEV double ik_diff(const Xf& P, const Xf& E, double* d) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = P.t[i] - E.t[i];
+    double R[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[i][j] = NBK_FMA(P.R[3 * i + 2], E.R[3 * j + 2], NBK_FMA(P.R[3 * i + 1], E.R[3 * j + 1], P.R[3 * i] * E.R[3 * j]));
+    d[3] = 0.5 * (R[2][1] - R[1][2]);
+    d[4] = 0.5 * (R[0][2] - R[2][0]);
+    d[5] = 0.5 * (R[1][0] - R[0][1]);
+    double s = d[0] * d[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) s = NBK_FMA(d[i], d[i], s);
+    return nbk_sqrt(s);
+}
+
+// x = (J J^T + lambda I)^-1 d by Cholesky; false when a pivot is not positive
+NBK_DEV bool ik_solve(const double* lds_J, int nq, int lane, double lambda, const double* d, double* x) {
+    double A[6][6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) A[r][c] = 0.0;
+    for (int j = 0; j < nq; ++j) {
+        double cj[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) cj[r] = lds_J[(r * nq + j) * WAVE + lane];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) A[r][c] = NBK_FMA(cj[r], cj[c], A[r][c]);
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) A[r][r] = A[r][r] + lambda;
+    double L[6][6];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[j][i];
+#pragma unroll
+            for (int k = 0; k < j; ++k) sum = NBK_FMA(-L[i][k], L[j][k], sum);
+            if (i == j) { if (!(sum > 0.0)) ok = false; L[i][i] = nbk_sqrt(sum); }
+            else L[i][j] = sum / L[j][j];
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double sum = d[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum = NBK_FMA(-L[i][k], y[k], sum);
+        y[i] = sum / L[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double sum = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) sum = NBK_FMA(-L[k][i], x[k], sum);
+        x[i] = sum / L[i][i];
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(64) void k_ik(DevModel m, PathArg path, IkArg arg, const double* __restrict__ pose,
+                                            const double* __restrict__ q0, int64_t B, double* __restrict__ q_out,
+                                            uint8_t* __restrict__ success, double* __restrict__ diff_norm, int32_t* __restrict__ iters) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int nq = m.n_q;
+    const int64_t b = (int64_t)blockIdx.x * WAVE + lane;
+    const bool active = b < B;
+    double* lds_q = lds;
+    double* lds_J = lds_q + WAVE * nq;
+    double* lds_jz = lds_J + WAVE * 6 * nq;
+    for (int j = 0; j < nq; ++j) lds_q[j * WAVE + lane] = active ? q0[b * nq + j] : 0.0;
+    for (int r = 0; r < 6 * nq; ++r) lds_J[r * WAVE + lane] = 0.0;
+    Xf P;
+    xf_from12(m.base_pose, P);
+    if (active) xf_from12(pose + 16 * b, P);
+    Xf E;
+    ik_sweep(m, path, lds_q, lds_J, lds_jz, lane, E);
+    double d[6];
+    double nrm = ik_diff(P, E, d);
+    double lambda = 1e-1;
+    int fail = 0, used = 0;
+    bool running = active && (nrm > arg.tol) && (fail < arg.max_failures);
+    for (int it = 0; it < arg.max_iter; ++it) {
+        if (__builtin_amdgcn_ballot_w64(running) == 0ull) break;
+        if (running) {
+            double x[6];
+            const bool ok = ik_solve(lds_J, nq, lane, lambda, d, x);
+            if (!ok) {
+                fail = arg.max_failures;           // singular damped system: the element stops, unsolved
+            } else {
+                for (int j = 0; j < nq; ++j) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) acc = NBK_FMA(lds_J[(r * nq + j) * WAVE + lane], x[r], acc);
+                    double qj = lds_q[j * WAVE + lane] + acc;
+                    if (arg.use_limits) { if (qj < arg.lo[j]) qj = arg.lo[j]; if (qj > arg.hi[j]) qj = arg.hi[j]; }
+                    lds_q[j * WAVE + lane] = qj;
+                }
+                ik_sweep(m, path, lds_q, lds_J, lds_jz, lane, E);
+                const double prev = nrm;
+                nrm = ik_diff(P, E, d);
+                const bool grew = nrm > prev;
+                lambda = lambda * (grew ? 1.2 : 0.5);
+                fail = grew ? fail + 1 : 0;
+                used += 1;
+            }
+        }
+        running = running && (nrm > arg.tol) && (fail < arg.max_failures);
+    }
+    if (active) {
+        for (int j = 0; j < nq; ++j) q_out[b * nq + j] = lds_q[j * WAVE + lane];
+        success[b] = (nrm < arg.tol) ? 1 : 0;
+        if (diff_norm != nullptr) diff_norm[b] = nrm;
+        if (iters != nullptr) iters[b] = used;
+    }
+}
+
 // ---- collision: sweep the tree, park robot cores in LDS ---------------------------------------------
 // LDS rows of 64 doubles: [n_q q rows][shape_rows][frame_slots * 12]
 // lds_jz (optional): [J][6] rows -- world axis w_k = R_k a_k and origin o_k of every joint, for Jacobian rows
@@ -2092,6 +2265,28 @@ int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const
     const size_t lds = sizeof(double) * WAVE * ((size_t)m->n_q + (size_t)stride);
     if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_jacobian, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, mode, pose, J_out);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_ik_batch(const nbk_model* m, const double* pose, const double* q0, int64_t B, const int32_t* path, int32_t path_len,
+                     const double* local, const double* limits, double tol, int32_t max_iter, int32_t max_failures,
+                     double* q_out, uint8_t* success, double* diff_norm, int32_t* iters, void* stream) {
+    if (m == nullptr || B < 0 || (B > 0 && (pose == nullptr || q0 == nullptr || q_out == nullptr || success == nullptr))) return NBK_ERR_INVALID;
+    if (max_iter < 1 || max_failures < 0 || !(tol >= 0.0)) return NBK_ERR_INVALID;
+    PathArg pa;
+    const int st = make_path(m, path, path_len, local, pa);
+    if (st != NBK_OK) return st;
+    if (B == 0) return NBK_OK;
+    IkArg arg;
+    memset(&arg, 0, sizeof(arg));
+    arg.tol = tol; arg.max_iter = max_iter; arg.max_failures = max_failures; arg.use_limits = limits != nullptr ? 1 : 0;
+    if (limits != nullptr)
+        for (int j = 0; j < m->n_q; ++j) { arg.lo[j] = limits[2 * j]; arg.hi[j] = limits[2 * j + 1]; }
+    const size_t lds = sizeof(double) * WAVE * ((size_t)m->n_q * 7 + 6 * (size_t)(pa.len > 0 ? pa.len : 1));
+    if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_ik, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, arg, pose, q0, B, q_out, success,
+                       diff_norm, iters);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }

@@ -146,6 +146,25 @@ class DeviceModel:
                                                 out.data_ptr(), self._stream()), "nbk_jacobian_batch")
         return qs.out(out)
 
+    def ik(self, pose, q0, frame, extra_local=None, limits=None, tol=1e-6, max_iter=100, max_failures=15):
+        """B damped-least-squares IK problems of one frame -> (success (B,) bool, q (B,n_q), |diff| (B,), steps (B,))."""
+        torch = _require_gpu()
+        qs = _Staged(q0, self.n_q)
+        ps = _Staged(pose, 16, "pose")
+        if ps.B != qs.B:
+            raise ValueError("pose and q0 must have the same number of rows")
+        path, local = self._frame_args(frame, extra_local)
+        lim = None if limits is None else _host_f64(limits, 2 * self.n_q)
+        q = torch.empty((qs.B, self.n_q), dtype=torch.float64, device=qs.device)
+        ok = torch.empty((qs.B,), dtype=torch.uint8, device=qs.device)
+        nrm = torch.empty((qs.B,), dtype=torch.float64, device=qs.device)
+        it = torch.empty((qs.B,), dtype=torch.int32, device=qs.device)
+        _lib.check(self._lib.nbk_ik_batch(self._h, ps.t.data_ptr(), qs.t.data_ptr(), qs.B, path.ctypes.data, len(path),
+                                          local.ctypes.data, None if lim is None else lim.ctypes.data, float(tol),
+                                          int(max_iter), int(max_failures), q.data_ptr(), ok.data_ptr(), nrm.data_ptr(),
+                                          it.data_ptr(), self._stream()), "nbk_ik_batch")
+        return qs.out(ok.bool()), qs.out(q), qs.out(nrm), qs.out(it)
+
     # ---- collision -----------------------------------------------------------------------------
     def validity_workspace_bytes(self, B: int) -> int:
         return int(self._lib.nbk_validity_workspace_bytes(self._h, int(B)))

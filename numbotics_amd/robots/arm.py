@@ -337,8 +337,54 @@ class Arm(Robot):
             return J[0]
         return J.reshape(*shape[:-1], 6, self.dof)
 
-    def inverse_kinematics(self, *args, **kwargs):
-        raise NotImplementedError("batched Levenberg-Marquardt IK is a SURVEY.md section 8(f) 'next' row (rank 3)")
+    def inverse_kinematics(self, pose, q0, frame: str, use_com: bool = False, use_limits: bool = False,
+                           tol: float = 1e-6, max_iter: int = 100, max_failures: int = 15):
+        """Damped-least-squares IK, signature and return shapes of upstream (arm.py:464-552): ``(success, q)`` with
+        ``success`` a flat bool array and ``q`` shaped ``(dof,)`` or ``(*batch_dims, dof)``.  All problems iterate
+        inside one launch (``nbk_ik_batch``).  Upstream's own loop cannot run (its ``jacobian`` call hits Q2); the
+        per-element arithmetic it writes down is what the kernel follows, with a Cholesky solve for LAPACK's LU."""
+        if frame not in self._kin.frames:
+            raise ValueError(f"Frame {frame} not found in chain")
+        if q0.shape[-1] != self.dof:
+            raise ValueError(f"q0 must have {self.dof} elements")
+        if max_iter < 1:
+            raise ValueError("max_iter must be greater than 0")
+        if tuple(pose.shape[-2:]) != (4, 4):
+            raise ValueError("pose must be a 4x4 matrix")
+        batch_dims = None
+        if pose.ndim > 2:
+            batch_dims = tuple(pose.shape[:-2])
+            pose = pose.reshape(-1, 4, 4)
+        if q0.ndim > 1:
+            if batch_dims:
+                if tuple(q0.shape[:-1]) != batch_dims:
+                    raise ValueError("pose and q0 must have the same batch dimensions")
+            else:
+                batch_dims = tuple(q0.shape[:-1])
+        q0f = q0.reshape(-1, self.dof)
+        posef = pose.reshape(-1, 4, 4)
+        n = max(int(q0f.shape[0]), int(posef.shape[0]))
+        if _is_tensor(q0f) or _is_tensor(posef):
+            import torch
+            q0f = q0f if _is_tensor(q0f) else torch.from_numpy(np.ascontiguousarray(q0f, dtype=np.float64))
+            posef = posef if _is_tensor(posef) else torch.from_numpy(np.ascontiguousarray(posef, dtype=np.float64))
+            if q0f.shape[0] != n:
+                q0f = q0f.expand(n, self.dof)
+            if posef.shape[0] != n:
+                posef = posef.expand(n, 4, 4)
+            q0f, posef = q0f.cuda(), posef.cuda()
+        else:
+            if q0f.shape[0] != n:
+                q0f = np.tile(q0f, (n, 1))
+            if posef.shape[0] != n:
+                posef = np.tile(posef, (n, 1, 1))
+        extra = self._links_from_nodes[frame]._offset if use_com else None
+        limits = np.ascontiguousarray(self.joint_limits, dtype=np.float64) if use_limits else None
+        ok, q, _, _ = self._kin_device().ik(posef, q0f, frame, extra_local=extra, limits=limits, tol=tol,
+                                            max_iter=max_iter, max_failures=max_failures)
+        if batch_dims is None:
+            return ok, q[0]
+        return ok, q.reshape(*batch_dims, self.dof)
 
     # ---- collision queries ------------------------------------------------------------------------------
     def _proximities(self, q, sm, dist, wit):

@@ -129,6 +129,18 @@ class Oracle:
         return out
 
     # ---- collision -----------------------------------------------------------------------------
+    def ik(self, pose, q0, frame, extra_local=None, limits=None, tol=1e-6, max_iter=100, max_failures=15):
+        q0 = _f64(q0, (-1, self.n_q))
+        B = q0.shape[0]
+        pose = _f64(pose, (B, 16))
+        path, local = self._frame(frame, extra_local)
+        lim = None if limits is None else _f64(limits, (self.n_q, 2))
+        q = np.empty((B, self.n_q)); ok = np.empty((B,), dtype=np.uint8); nrm = np.empty((B,)); it = np.empty((B,), dtype=np.int32)
+        lib().orc_ik(C.byref(self._m), _p(pose), _p(q0), C.c_int64(B), _p(path), C.c_int32(len(path)), _p(local),
+                     None if lim is None else _p(lim), C.c_double(tol), C.c_int32(max_iter), C.c_int32(max_failures),
+                     _p(q), _p(ok), _p(nrm), _p(it))
+        return ok.astype(bool), q, nrm, it
+
     def pair_distances(self, q, witness=False):
         q = _f64(q, (-1, self.n_q))
         B = q.shape[0]

@@ -205,6 +205,123 @@ int orc_jacobian(const orc_model *m, const double *q, int64_t B, const int32_t *
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * Levenberg-Marquardt inverse kinematics (numbotics/robots/arm.py:464-552; rot_diff: numbotics/math/spatial.py:207-212)
+ * ---------------------------------------------------------------------------------------------- */
+static double ik_diff(const xf_t *P, const xf_t *E, double *d) {
+    for (int i = 0; i < 3; ++i) d[i] = P->t[i] - E->t[i];
+    double R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            R[i][j] = FMA(P->R[3 * i + 2], E->R[3 * j + 2], FMA(P->R[3 * i + 1], E->R[3 * j + 1], P->R[3 * i] * E->R[3 * j]));
+    d[3] = 0.5 * (R[2][1] - R[1][2]);
+    d[4] = 0.5 * (R[0][2] - R[2][0]);
+    d[5] = 0.5 * (R[1][0] - R[0][1]);
+    double s = d[0] * d[0];
+    for (int i = 1; i < 6; ++i) s = FMA(d[i], d[i], s);
+    return sqrt(s);
+}
+
+/* pose of the frame and its 6 x n_q Jacobian (rows [v; w], as orc_jacobian mode 0) at q */
+static void ik_sweep(const orc_model *m, const double *q, const int32_t *path, int32_t path_len, const xf_t *loc,
+                     xf_t *frames, double *J, xf_t *E) {
+    xf_t T;
+    const int nq = m->n_q;
+    sweep_path(m, q, path, path_len, &T, frames);
+    xf_mul(&T, loc->R, loc->t, E);
+    for (int i = 0; i < path_len; ++i) {
+        const int k = path[i];
+        const double *a = m->joint_axis + 3 * k;
+        const xf_t *F = &frames[i];
+        double w[3];
+        for (int r = 0; r < 3; ++r) w[r] = FMA(F->R[3 * r + 2], a[2], FMA(F->R[3 * r + 1], a[1], F->R[3 * r] * a[0]));
+        const int col = m->joint_qidx[k];
+        if (m->joint_type[k] == ORC_REVOLUTE) {
+            double d[3], v[3];
+            sub3(E->t, F->t, d);
+            cross3(w, d, v);
+            for (int r = 0; r < 3; ++r) { J[r * nq + col] = v[r]; J[(3 + r) * nq + col] = w[r]; }
+        } else {
+            for (int r = 0; r < 3; ++r) { J[r * nq + col] = w[r]; J[(3 + r) * nq + col] = 0.0; }
+        }
+    }
+}
+
+static int ik_solve(const double *J, int nq, double lambda, const double *d, double *x) {
+    double A[6][6], L[6][6], y[6];
+    int ok = 1;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) A[r][c] = 0.0;
+    for (int j = 0; j < nq; ++j)
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) A[r][c] = FMA(J[r * nq + j], J[c * nq + j], A[r][c]);
+    for (int r = 0; r < 6; ++r) A[r][r] = A[r][r] + lambda;
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[j][i];
+            for (int k = 0; k < j; ++k) sum = FMA(-L[i][k], L[j][k], sum);
+            if (i == j) { if (!(sum > 0.0)) ok = 0; L[i][i] = sqrt(sum); }
+            else L[i][j] = sum / L[j][j];
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        double sum = d[i];
+        for (int k = 0; k < i; ++k) sum = FMA(-L[i][k], y[k], sum);
+        y[i] = sum / L[i][i];
+    }
+    for (int i = 5; i >= 0; --i) {
+        double sum = y[i];
+        for (int k = i + 1; k < 6; ++k) sum = FMA(-L[k][i], x[k], sum);
+        x[i] = sum / L[i][i];
+    }
+    return ok;
+}
+
+int orc_ik(const orc_model *m, const double *pose, const double *q0, int64_t B, const int32_t *path, int32_t path_len,
+           const double *local, const double *limits, double tol, int32_t max_iter, int32_t max_failures,
+           double *q_out, uint8_t *success, double *diff_norm, int32_t *iters) {
+    const int nq = m->n_q;
+    xf_t loc;
+    xf_from12(local, &loc);
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(path_len > 0 ? path_len : 1));
+    double *J = (double *)malloc(sizeof(double) * 6 * (size_t)nq);
+    if (!frames || !J) { free(frames); free(J); return -1; }
+    for (int64_t b = 0; b < B; ++b) {
+        double *q = q_out + b * nq;
+        memcpy(q, q0 + b * nq, sizeof(double) * (size_t)nq);
+        memset(J, 0, sizeof(double) * 6 * (size_t)nq);
+        xf_t P, E;
+        xf_from12(pose + 16 * b, &P);
+        ik_sweep(m, q, path, path_len, &loc, frames, J, &E);
+        double d[6], x[6];
+        double nrm = ik_diff(&P, &E, d);
+        double lambda = 1e-1;
+        int fail = 0, used = 0;
+        for (int it = 0; it < max_iter; ++it) {
+            if (!((nrm > tol) && (fail < max_failures))) break;
+            if (!ik_solve(J, nq, lambda, d, x)) { fail = max_failures; continue; }
+            for (int j = 0; j < nq; ++j) {
+                double acc = 0.0;
+                for (int r = 0; r < 6; ++r) acc = FMA(J[r * nq + j], x[r], acc);
+                double qj = q[j] + acc;
+                if (limits) { if (qj < limits[2 * j]) qj = limits[2 * j]; if (qj > limits[2 * j + 1]) qj = limits[2 * j + 1]; }
+                q[j] = qj;
+            }
+            ik_sweep(m, q, path, path_len, &loc, frames, J, &E);
+            const double prev = nrm;
+            nrm = ik_diff(&P, &E, d);
+            const int grew = nrm > prev;
+            lambda = lambda * (grew ? 1.2 : 0.5);
+            fail = grew ? fail + 1 : 0;
+            used += 1;
+        }
+        success[b] = (nrm < tol) ? 1 : 0;
+        if (diff_norm) diff_norm[b] = nrm;
+        if (iters) iters[b] = used;
+    }
+    free(frames); free(J);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * narrowphase.  Every shape = convex core (+) ball(margin):
  *   sphere   : point,            margin r
  *   capsule  : segment c +- hl u, margin r            (u = local z)

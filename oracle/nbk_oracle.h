@@ -71,6 +71,13 @@ int orc_fk(const orc_model *m, const double *q, int64_t B, const int32_t *path, 
 int orc_jacobian(const orc_model *m, const double *q, int64_t B, const int32_t *path, int32_t path_len,
                  const double *local, int32_t mode, const double *pose, double *out);
 
+/* Arm.inverse_kinematics (numbotics/robots/arm.py:464-552) for B (pose, q0) problems of one frame; limits (optional)
+ * [n_q][2]; success[b] = |diff| < tol.  The damped 6x6 system is solved by an unpivoted Cholesky (the reference calls
+ * np.linalg.solve): equal to rounding, not bit for bit -- tests/test_oracle_ik.py holds the NumPy restatement. */
+int orc_ik(const orc_model *m, const double *pose, const double *q0, int64_t B, const int32_t *path, int32_t path_len,
+           const double *local, const double *limits, double tol, int32_t max_iter, int32_t max_failures,
+           double *q_out, uint8_t *success, double *diff_norm, int32_t *iters);
+
 /* signed distance of every allowed pair: dist [B][P]; witness (optional) [B][P][9] =
  * point on A, point on B, unit normal from B to A. */
 int orc_pair_distances(const orc_model *m, const double *q, int64_t B, double *dist, double *witness);

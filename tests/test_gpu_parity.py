@@ -453,6 +453,79 @@ def test_proximity_jacobian_rows(fresh_world, scene, torch_cuda):
     assert lib.nbk_proximity_jacobian_batch(dev._h, qt.data_ptr(), 0, None, None, None, st) == 0
 
 
+def test_inverse_kinematics(kinova, torch_cuda):
+    """SURVEY.md 8(f) rank 3: batched Levenberg-Marquardt IK (arm.py:464-552), all problems inside one launch;
+    iterates, flags, residuals and step counts bit-exact against the oracle (tests/test_oracle_ik.py ties the oracle
+    to the NumPy restatement of the reference loop)."""
+    import ctypes as C
+    arm, chain, obs = kinova
+    orc = Oracle(arm._kin)
+    _ = arm._kin_device()
+    rng = np.random.default_rng(3)
+    n = 5000
+    qt = sample_q(chain, n, seed=13, margin=0.2)
+    limits = np.asarray(chain.joint_limits, dtype=np.float64)
+    dev = arm._kin_device()
+    for frame, spread, lim in (("tool_frame", 0.5, None), ("tool_frame", 3.0, limits), ("bracelet_link", 1.0, None)):
+        pose = orc.fk(qt, frame)
+        q0 = qt + rng.uniform(-spread, spread, qt.shape)
+        ok, q, nrm, it = dev.ik(pose, q0, frame, limits=lim)
+        okr, qr, nrmr, itr = orc.ik(pose, q0, frame, limits=lim)
+        assert np.array_equal(ok, okr) and np.array_equal(it, itr)
+        assert_bitwise(q, qr, f"ik q {frame}")
+        assert_bitwise(nrm, nrmr, f"ik residual {frame}")
+        assert ok.mean() > (0.9 if spread < 1.0 else 0.2)
+        T = arm.forward_kinematics(q[ok], frame)
+        assert np.abs(T[:, :3, 3] - pose[ok][:, :3, 3]).max() < 1e-6
+    # upstream's signature and return shapes (arm.py:548-552)
+    pose = orc.fk(qt[:8], "tool_frame")
+    ok1, q1 = arm.inverse_kinematics(pose[0], qt[0] + 0.1, "tool_frame")
+    assert ok1.shape == (1,) and q1.shape == (7,) and ok1[0]
+    okb, qb = arm.inverse_kinematics(pose, qt[:8] + 0.1, "tool_frame", use_limits=True)
+    assert okb.shape == (8,) and qb.shape == (8, 7) and okb.all()
+    okc, qc = arm.inverse_kinematics(pose[0], qt[:8] + 0.1, "tool_frame")            # one pose, many starts
+    assert okc.shape == (8,) and qc.shape == (8, 7)
+    okd, qd = arm.inverse_kinematics(pose.reshape(2, 4, 4, 4), (qt[:8] + 0.1).reshape(2, 4, 7), "tool_frame", use_com=True)
+    assert okd.shape == (8,) and qd.shape == (2, 4, 7)
+    Tc = arm.forward_kinematics(qd[0, 0], "tool_frame", use_com=True)
+    assert np.abs(Tc[:3, 3] - pose[0][:3, 3]).max() < 1e-6
+    qt_t = torch_cuda.from_numpy(qt[:8] + 0.1).cuda()
+    okt, qtt = arm.inverse_kinematics(torch_cuda.from_numpy(pose).cuda(), qt_t, "tool_frame")
+    assert qtt.is_cuda and np.array_equal(qtt.cpu().numpy(), arm.inverse_kinematics(pose, qt[:8] + 0.1, "tool_frame")[1])
+    with pytest.raises(ValueError):
+        arm.inverse_kinematics(pose[0], qt[0], "nope")
+    with pytest.raises(ValueError):
+        arm.inverse_kinematics(pose[0], qt[0][:6], "tool_frame")
+    with pytest.raises(ValueError):
+        arm.inverse_kinematics(pose[0], qt[0], "tool_frame", max_iter=0)
+    with pytest.raises(ValueError):
+        arm.inverse_kinematics(pose[:4], qt[:8], "tool_frame")
+    from numbotics_amd import _lib
+    lib = _lib.load()
+    assert lib.nbk_ik_batch(dev._h, None, qt_t.data_ptr(), 8, None, 0, None, None, 1e-6, 100, 15, None, None, None, None, None) == -1
+
+
+def test_inverse_kinematics_tree_robot(fresh_world, torch_cuda):
+    arm, chain, obs = _tree_scene()
+    orc = Oracle(arm._kin)
+    dev = arm._kin_device()
+    rng = np.random.default_rng(5)
+    qt = sample_q(chain, 2000, seed=17)
+    for frame in ("tip_b", "wrist_cam"):          # 3-4 joints on the path: the damping carries the rank-deficient system
+        pose = orc.fk(qt, frame)
+        q0 = qt + rng.uniform(-0.2, 0.2, qt.shape)
+        ok, q, nrm, it = dev.ik(pose, q0, frame)
+        okr, qr, nrmr, itr = orc.ik(pose, q0, frame)
+        assert np.array_equal(ok, okr) and np.array_equal(it, itr)
+        assert_bitwise(q, qr, f"tree ik q {frame}")
+        assert_bitwise(nrm, nrmr, f"tree ik residual {frame}")
+        # joints off the path are never touched
+        path_cols = set(int(arm._kin.joint_qidx[k]) for k in arm._kin.frames[frame].path)
+        for j in range(chain.dof):
+            if j not in path_cols:
+                assert np.array_equal(q[:, j], q0[:, j])
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
