@@ -64,7 +64,8 @@ struct DevModel {
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
                                   //        index into the vp_* tables, category (0 plane, 1 robot-robot, 2 robot-world, 3 robot-world box)
     int dbg;                              // ablation switches for profiling runs (NBK_ABLATE env): 1 = no narrowphase, 2 = no pair loop,
-                                          // 4 = no queue appends, 8 = no GJK phase, 16 = no FK replay, 32 = no cores, 64 = no pre-check
+                                          // 4 = no queue appends, 8 = no GJK phase, 16 = no FK replay, 32 = no cores, 64 = no pre-check,
+                                          // 128 = k_narrow accumulates per-phase cycle counts (tools/narrow_prof.py)
 };
 
 }  // namespace nbk
@@ -1315,6 +1316,10 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
 
 // BOOL_ONLY: the host has established tc == 0 for every pair (threshold 0, no margins -- the reference's default
 // in_collision(q) call); only the boolean GJK state is kept, which removes the register spills of the general form.
+// in-kernel phase timing of k_narrow (NBK_ABLATE bit 128): per working wave, cycles between stamps, summed
+__device__ unsigned long long g_narrow_prof[16];
+#define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
+
 template <bool BOOL_ONLY, int POOL_CAP>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
                          const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
@@ -1328,6 +1333,9 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     // The kernel is latency-bound, so dependent global round trips are kept to three: {count, first item} ->
     // {pair record, q row} -> shape constants.  The first chunk's item is loaded before the count is known (the slot
     // is inside the allocated sub-queue either way; its value is used only when the slot is below the count).
+    const bool prof = (m.dbg & 128) != 0;
+    unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    NBK_STAMP(0);
     q_items += (unsigned long long)sub * cap;
     const unsigned long long i_first = (unsigned long long)part * NARROW_T + threadIdx.x;
     unsigned long long item_first = 0;
@@ -1350,6 +1358,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             const long long b = (long long)(item >> 20);
             const int p = (int)(item & 0xFFFFFull);
             // dead lanes read record 0 / row 0 of this tile (valid memory) and discard it
+            NBK_STAMP(1);
             const int4 info = m.vp_info[p];
             const int ra = live ? info.x : -1, rb = live ? info.y : -1;
             const unsigned ma = live ? (unsigned)info.z : 0u, mb = live ? (unsigned)info.w : 0u;
@@ -1385,6 +1394,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                         if (j0 + u <= nq1) myq[j0 + u] = qv[u];
                 }
             }
+            NBK_STAMP(2);
             for (int k = 0; k < ((m.dbg & 16) ? 0 : m.n_joints); ++k) {
                 const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
                 if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
@@ -1396,12 +1406,15 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                     if (in_b) TB = nxt;
                 }
             }
+            NBK_STAMP(3);
             bool pooled = false;
             Core A, Bc;
             double tc = 0.0;
             if (live && !(m.dbg & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
+                if (prof) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; if (acc == 12345.678) mark_hit(b, mask_bits, mask_bytes); }
+                NBK_STAMP(4);
                 const double* cst = m.vp_cst + 4 * p;
                 int verdict;
                 if (m.dbg & 64) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[1][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[1][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; verdict = (acc == 12345.678) ? 1 : 0; }
@@ -1427,6 +1440,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             }
         }
         __syncthreads();
+        NBK_STAMP(5);
         // ---- phase 2 -----------------------------------------------------------------------------------------------
         {
             const int np = (m.dbg & 8) ? 0 : (pool_n < POOL_CAP ? pool_n : POOL_CAP);
@@ -1496,6 +1510,16 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             }
         }
         __syncthreads();
+        if (prof && i0 == (unsigned long long)part * NARROW_T) {
+            NBK_STAMP(6);
+            if (threadIdx.x == 0) {
+                for (int e = 0; e < 6; ++e) atomicAdd(&g_narrow_prof[e], stamp[e + 1] - stamp[e]);
+                atomicAdd(&g_narrow_prof[15], 1ull);
+                atomicMax(&g_narrow_prof[14], stamp[6] - stamp[0]);
+                atomicMin(&g_narrow_prof[13], stamp[0]);
+                atomicMax(&g_narrow_prof[12], stamp[6]);
+            }
+        }
     }
 }
 
@@ -2221,6 +2245,13 @@ void nbk_model_destroy(nbk_model* m) {
     if (m->ws) (void)hipFree(m->ws);
     if (m->ews) (void)hipFree(m->ews);
     delete m;
+}
+
+// diagnostic (not part of include/nbk.h): cycles per phase of k_narrow accumulated since the last reset, out[16]
+extern "C" int32_t nbk_debug_narrow_profile(unsigned long long* out, int32_t reset) {
+    if (out != nullptr) NBK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(nbk::g_narrow_prof), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; z[13] = ~0ull; NBK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nbk::g_narrow_prof), z, sizeof(z))); }
+    return NBK_OK;
 }
 
 int32_t nbk_model_num_pairs(const nbk_model* m) { return m ? m->n_pairs : NBK_ERR_INVALID; }
