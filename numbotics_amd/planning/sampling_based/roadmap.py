@@ -1,0 +1,247 @@
+"""PRM with the edge checks of a whole roadmap in one device call.
+
+Reference: numbotics/planning/sampling_based/{space.py:8-46, base.py:15-72, planners/prm.py:13-47,
+graph.py:32-72,158-233}.  The reference's loop adds one sample per iteration, asks faiss for its k nearest
+vertices and calls ``connector.connect`` once per neighbour (``prm.py:35-47``) -- ``max_iters * k_nearest``
+sequential edge walks, each ``ceil(d/res)+1`` PyBullet queries.  The roadmap those iterations build depends only
+on the sample sequence: vertex i is connected to its k nearest among the vertices that existed when it was added
+(itself included, which ``connect`` rejects as a zero-length edge).  ``PRM.plan`` therefore draws the samples
+exactly as ``SamplingPlannerBase.sample_state`` does, finds every neighbour list with an exact float32 L2 scan
+(what ``faiss.IndexFlatL2`` computes; faiss itself is a third-party dependency, tie-breaking parity unpinned),
+and hands ALL candidate edges to ``DiscreteConnector.connect_batch`` -- one launch sequence on the device.
+
+Only what PRM needs is here: the state space, the planner parameters, the roadmap (arrays + a SciPy Dijkstra
+instead of networkx).  RRT/RRT* grow a tree one steer at a time and stay sequential (``steer`` already checks a
+whole edge per call).
+"""
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from random import choice
+from typing import Callable, List, Optional
+
+import numpy as np
+
+
+class StateSpace(ABC):
+    """space.py:8-46."""
+
+    def __init__(self, lower_bounds, upper_bounds, sampler: Optional[Callable] = None):
+        self._lower_bounds = lower_bounds
+        self._upper_bounds = upper_bounds
+        if self._lower_bounds.shape != self._upper_bounds.shape:
+            raise ValueError("Lower and upper bounds must have the same shape")
+        if self._lower_bounds.ndim != 1:
+            raise ValueError("Lower and upper bounds must be 1D arrays")
+        self._sampler = sampler
+
+    def sample(self):
+        if self._sampler is None:
+            return np.random.uniform(self.lower_bounds, self.upper_bounds)
+        return self._sampler()
+
+    @abstractmethod
+    def distance(self, state1, state2):
+        raise NotImplementedError
+
+    def distance_batch(self, states1, states2):
+        """Row-wise ``distance``; subclasses may vectorise it as long as every row equals the scalar call bit for bit
+        (the edge sampling step is ``resolution / distance``)."""
+        return np.array([self.distance(a, b) for a, b in zip(states1, states2)], dtype=np.float64)
+
+    @property
+    def lower_bounds(self):
+        return self._lower_bounds
+
+    @property
+    def upper_bounds(self):
+        return self._upper_bounds
+
+    @property
+    def dimension(self):
+        return self._lower_bounds.shape[0]
+
+    @property
+    def volume(self):
+        return np.prod(self._upper_bounds - self._lower_bounds)
+
+
+class EuclideanSpace(StateSpace):
+    """L2 metric.  The scalar form goes through the same row reduction as the batched one, so both give identical bits."""
+
+    def distance(self, state1, state2):
+        return float(self.distance_batch(np.asarray(state1)[None], np.asarray(state2)[None])[0])
+
+    def distance_batch(self, states1, states2):
+        d = np.ascontiguousarray(np.asarray(states1, dtype=np.float64) - np.asarray(states2, dtype=np.float64))
+        return np.sqrt((d * d).sum(axis=-1))
+
+
+@dataclass(frozen=True)
+class PlannerParams:
+    """base.py:15-21."""
+    max_iters: int
+    goal_bias: float = 0.1
+    rewire_factor: float = 1.1
+    k_nearest: int = 50
+    goal_tolerance: float = 1e-6
+
+
+@dataclass(frozen=True)
+class Node:
+    """graph.py:10-19."""
+    id: str
+    state: np.ndarray
+    cost: float = np.inf
+
+
+def knn_prefix(points: np.ndarray, k: int, chunk: int = 2048):
+    """For every i: the indices of the (at most k) nearest points among points[0..i] (float32 squared L2, ascending,
+    ties to the smaller index) -- the neighbour lists an insert-then-query loop over an exact flat index yields.
+    -> (N, k) int64, -1 padded."""
+    x = np.ascontiguousarray(points, dtype=np.float32)
+    n = x.shape[0]
+    out = np.full((n, k), -1, dtype=np.int64)
+    sq = (x * x).sum(axis=1)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        d = sq[a:b, None] - 2.0 * (x[a:b] @ x[:b].T) + sq[None, :b]
+        d[np.arange(b - a)[:, None] + a < np.arange(b)[None, :]] = np.inf        # only points that already exist
+        kk = min(k, b)
+        # the kk smallest of every row without sorting the row: partition, then resolve ties at the k-th value
+        # towards the smaller index, then order the selection by (distance, index)
+        kth = np.partition(d, kk - 1, axis=1)[:, kk - 1]
+        lt = d < kth[:, None]
+        eq = d == kth[:, None]
+        need = kk - lt.sum(axis=1)
+        if (eq.sum(axis=1) == need).all():
+            sel = lt | eq
+        else:
+            sel = lt | (eq & (np.cumsum(eq, axis=1, dtype=np.int32) <= need[:, None]))
+        cols = np.nonzero(sel)[1].reshape(b - a, kk)                       # ascending index inside a row
+        dsel = np.take_along_axis(d, cols, axis=1)
+        order = np.argsort(dsel, axis=1, kind="stable")
+        idx = np.take_along_axis(cols, order, axis=1)
+        valid = np.take_along_axis(dsel, order, axis=1) < np.inf
+        out[a:b, :kk] = np.where(valid, idx, -1)
+    return out
+
+
+class PRM:
+    """prm.py:13-47 with the per-neighbour ``connect`` calls of all iterations batched."""
+
+    def __init__(self, space: StateSpace, connector, params: PlannerParams):
+        self._space = space
+        self._connector = connector
+        self._params = params
+        self._start = None
+        self._goals: List[np.ndarray] = []
+        self.states = None           # (V, d) vertex states, v_0 = start
+        self.edges = None            # (M, 2) int64 into the node list [vertices..., goals...]
+        self.weights = None          # (M,)
+        self.n_candidate_edges = 0
+
+    # base.py:45-71
+    def add_start(self, start):
+        if not self._connector.is_valid(start):
+            raise ValueError("Start state is invalid")
+        if not np.all(start >= self._space.lower_bounds) or not np.all(start <= self._space.upper_bounds):
+            raise ValueError("Start state is out of bounds")
+        self._start = start
+
+    def add_goal(self, goal):
+        if not self._connector.is_valid(goal):
+            raise ValueError("Goal state is invalid")
+        if not np.all(goal >= self._space.lower_bounds) or not np.all(goal <= self._space.upper_bounds):
+            raise ValueError("Goal state is out of bounds")
+        self._goals.append(goal)
+
+    def sample_state(self):
+        if self._start is None:
+            raise ValueError("Start state not set")
+        if len(self._goals) == 0:
+            raise ValueError("Goal states not set")
+        return choice(self._goals) if np.random.rand() < self._params.goal_bias else self._space.sample()
+
+    def candidate_edges(self, samples):
+        """The (neighbour, new node) pairs the reference loop would hand to ``connect`` for this sample sequence.
+        -> vertex states (V,d), edge list (M,2) of node indices (vertices first, then goals), per-edge distances."""
+        p = self._params
+        d = self._space.dimension
+        verts = [np.asarray(self._start, dtype=np.float64)]
+        targets = []                                   # per iteration: node index of new_node
+        goal_hits = []                                 # (iteration position, goal index, vertex count at that time)
+        for s in samples:
+            for gi, g in enumerate(self._goals):
+                if self._space.distance(s, g) < p.goal_tolerance:
+                    goal_hits.append((gi, len(verts)))
+                    targets.append(-1 - gi)
+                    break
+            else:
+                verts.append(np.asarray(s, dtype=np.float64))
+                targets.append(len(verts) - 1)
+        V = np.vstack(verts).reshape(-1, d)
+        nv = V.shape[0]
+        nbr = knn_prefix(V, p.k_nearest)
+        src, dst = [], []
+        for t in targets:
+            if t >= 0:
+                row = nbr[t]
+                row = row[row >= 0]
+                src.append(row)
+                dst.append(np.full(row.shape, t, dtype=np.int64))
+        # a sample that landed on a goal: k nearest vertices of the goal state among those present at that time
+        x32 = V.astype(np.float32)
+        for gi, count in goal_hits:
+            g32 = np.asarray(self._goals[gi], dtype=np.float32)
+            dd = ((x32[:count] - g32) ** 2).sum(axis=1)
+            row = np.argsort(dd, kind="stable")[:p.k_nearest]
+            src.append(row.astype(np.int64))
+            dst.append(np.full(row.shape, nv + gi, dtype=np.int64))
+        src = np.concatenate(src) if src else np.zeros((0,), dtype=np.int64)
+        dst = np.concatenate(dst) if dst else np.zeros((0,), dtype=np.int64)
+        nodes = np.vstack([V] + [np.asarray(g, dtype=np.float64)[None] for g in self._goals])
+        dist = np.asarray(self._space.distance_batch(nodes[src], nodes[dst]), dtype=np.float64).reshape(-1)
+        return V, nodes, np.stack([src, dst], axis=1), dist
+
+    def plan(self, samples=None):
+        if self._start is None:
+            raise ValueError("Must set start state before planning")
+        if len(self._goals) == 0:
+            raise ValueError("Must set goal states before planning")
+        if samples is None:
+            samples = [self.sample_state() for _ in range(self._params.max_iters)]
+        V, nodes, cand, dist = self.candidate_edges(samples)
+        self.n_candidate_edges = int(cand.shape[0])
+        # zero-length edges (a vertex and itself) are what connect() refuses before looking at the scene
+        ok = np.zeros((cand.shape[0],), dtype=bool)
+        live = dist > np.finfo(np.float32).eps
+        if live.any():
+            ok[live] = np.asarray(self._connector.connect_batch(nodes[cand[live, 0]], nodes[cand[live, 1]], dist[live]))
+        self.states, self._nodes = V, nodes
+        self.edges, self.weights = cand[ok], dist[ok]
+        return self
+
+    def solution(self):
+        """Shortest start -> goal path over the roadmap (graph.py:199-233), as Nodes; None when no goal is reached."""
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import dijkstra
+        if self.edges is None or self.edges.shape[0] == 0:
+            return None
+        n = self._nodes.shape[0]
+        nv = self.states.shape[0]
+        # parallel edges (a pair proposed from both ends) collapse to one: COO construction would add their weights
+        key = np.sort(self.edges, axis=1)
+        _, first = np.unique(key, axis=0, return_index=True)
+        e, w = self.edges[first], self.weights[first]
+        g = coo_matrix((w, (e[:, 0], e[:, 1])), shape=(n, n)).tocsr()
+        dist, pred = dijkstra(g, directed=False, indices=0, return_predecessors=True)
+        goals = np.arange(nv, n)
+        best = goals[np.argmin(dist[goals])]
+        if not np.isfinite(dist[best]):
+            return None
+        path = [int(best)]
+        while path[-1] != 0:
+            path.append(int(pred[path[-1]]))
+        path.reverse()
+        name = lambda i: f"v_{i}" if i < nv else f"g_{i - nv}"      # noqa: E731
+        return [Node(id=name(i), state=self._nodes[i], cost=float(dist[i])) for i in path]

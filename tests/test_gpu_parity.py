@@ -526,6 +526,39 @@ def test_inverse_kinematics_tree_robot(fresh_world, torch_cuda):
                 assert np.array_equal(q[:, j], q0[:, j])
 
 
+def test_batched_prm_on_the_device(fresh_world, torch_cuda):
+    """every candidate edge of a PRM roadmap in one connect_batch call; the accepted edges are
+    exactly those the scalar connector.connect accepts, which in turn is the oracle's edge predicate."""
+    from numbotics_amd.planning.sampling_based import (ConnectorParams, DiscreteConnector, EuclideanSpace, PlannerParams, PRM)
+    arm, chain, obs = build_scene("c3")
+    lim = np.asarray(chain.joint_limits, dtype=np.float64)
+    space = EuclideanSpace(lim[:, 0].copy(), lim[:, 1].copy())
+    conn = DiscreteConnector(ConnectorParams(resolution=0.05, max_distance=np.pi, arm=arm))
+    rng = np.random.default_rng(8)
+    free = [s for s in sample_q(chain, 4000, seed=5) if conn.is_valid(s)]
+    start, goal = free[0], free[1]
+    params = PlannerParams(max_iters=600, k_nearest=10, goal_bias=0.02)
+    samples = [goal.copy() if rng.random() < params.goal_bias else s for s in free[2:2 + params.max_iters]]
+    prm = PRM(space, conn, params)
+    prm.add_start(start)
+    prm.add_goal(goal)
+    prm.plan(samples)
+    assert prm.n_candidate_edges > 5000 and 0.02 < prm.edges.shape[0] / prm.n_candidate_edges < 0.98
+    V, nodes, cand, dist = prm.candidate_edges(samples)
+    live = dist > np.finfo(np.float32).eps
+    orc = Oracle(arm.scene_model())
+    ok_ref, _, _ = orc.edge_validity(nodes[cand[live, 0]], nodes[cand[live, 1]], 0.05, np.pi, mode="connect", dist=dist[live], nthreads=8)
+    accepted = set(map(tuple, prm.edges.tolist()))
+    assert accepted == set(map(tuple, cand[live][ok_ref].tolist()))
+    for a, b in cand[live][:40]:                                   # the scalar contract agrees edge by edge
+        assert (conn.connect(nodes[a], nodes[b], distance_func=space.distance) is not None) == ((int(a), int(b)) in accepted)
+    path = prm.solution()
+    if path is not None:
+        assert path[0].id == "v_0" and path[-1].id == "g_0"
+        for a, b in zip(path[:-1], path[1:]):
+            assert conn.connect(a.state, b.state) is not None or conn.connect(b.state, a.state) is not None
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""

@@ -1,0 +1,96 @@
+"""Batched PRM (numbotics_amd/planning/sampling_based/roadmap.py) against the reference's sequential loop
+(numbotics/planning/sampling_based/planners/prm.py:19-47), restated here with an insert-then-query exact index."""
+import numpy as np
+import pytest
+
+from numbotics_amd.planning.sampling_based import EuclideanSpace, PlannerParams, PRM, knn_prefix
+
+
+class DiskWorldConnector:
+    """2-D world with one disk obstacle; connect = DiscreteConnector's sampling rule with a Python checker."""
+
+    def __init__(self, centre, radius, resolution=0.02):
+        self.c, self.r, self.res = np.asarray(centre), radius, resolution
+        self.calls = 0
+
+    def is_valid(self, s):
+        return np.linalg.norm(s - self.c) > self.r
+
+    def connect(self, a, b, distance_func=lambda x, y: np.linalg.norm(x - y)):
+        self.calls += 1
+        d = distance_func(a, b)
+        if d <= np.finfo(np.float32).eps:
+            return None
+        T = np.append(np.arange(0.0, 1.0, self.res / d), 1.0)
+        for t in T:
+            if not self.is_valid((1 - t) * a + t * b):
+                return None
+        return np.copy(b)
+
+    def connect_batch(self, A, B, dist=None):
+        return np.array([self.connect(a, b) is not None for a, b in zip(A, B)])
+
+
+def reference_loop(space, connector, params, start, goals, samples):
+    """prm.py:19-47 verbatim in structure: one vertex, one k-nearest query, k connects per iteration."""
+    verts = [start]
+    edges = []
+    for s in samples:
+        node = None
+        for gi, g in enumerate(goals):
+            if space.distance(s, g) < params.goal_tolerance:
+                node = ("g", gi, g)
+                break
+        else:
+            verts.append(s)
+            node = ("v", len(verts) - 1, s)
+        X = np.asarray(verts, dtype=np.float32)
+        d = ((X - np.asarray(node[2], dtype=np.float32)) ** 2).sum(axis=1)
+        near = np.argsort(d, kind="stable")[:params.k_nearest]
+        for j in near:
+            if connector.connect(verts[j], node[2], distance_func=space.distance) is not None:
+                edges.append((int(j), node[0], node[1]))
+    return verts, edges
+
+
+def test_batched_prm_builds_the_same_roadmap():
+    rng = np.random.default_rng(4)
+    space = EuclideanSpace(np.zeros(2), np.ones(2))
+    params = PlannerParams(max_iters=300, k_nearest=8, goal_bias=0.05)
+    start, goal = np.array([0.05, 0.05]), np.array([0.95, 0.95])
+    samples = [goal.copy() if rng.random() < params.goal_bias else rng.uniform(0, 1, 2) for _ in range(params.max_iters)]
+    ref_conn = DiskWorldConnector([0.5, 0.5], 0.25)
+    verts, ref_edges = reference_loop(space, ref_conn, params, start, [goal], samples)
+    conn = DiskWorldConnector([0.5, 0.5], 0.25)
+    prm = PRM(space, conn, params)
+    prm.add_start(start)
+    prm.add_goal(goal)
+    prm.plan(samples)
+    nv = prm.states.shape[0]
+    assert nv == len(verts) and np.array_equal(prm.states, np.asarray(verts))
+    got = sorted((int(a), "v" if b < nv else "g", int(b if b < nv else b - nv)) for a, b in prm.edges)
+    assert got == sorted(ref_edges) and len(got) > 200
+    assert prm.n_candidate_edges == ref_conn.calls                   # the same connect() calls, made at once
+    path = prm.solution()
+    assert path is not None and path[0].id == "v_0" and path[-1].id == "g_0"
+    for a, b in zip(path[:-1], path[1:]):                            # every hop is a checked edge
+        assert conn.connect(a.state, b.state) is not None
+    assert abs(path[-1].cost - sum(np.linalg.norm(a.state - b.state) for a, b in zip(path[:-1], path[1:]))) < 1e-12
+    with pytest.raises(ValueError):
+        PRM(space, conn, params).plan()
+    with pytest.raises(ValueError):
+        prm.add_start(np.array([0.5, 0.5]))                          # inside the obstacle
+    with pytest.raises(ValueError):
+        prm.add_goal(np.array([1.5, 0.5]))                           # out of bounds
+
+
+def test_knn_prefix_is_an_insert_then_query_index():
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(500, 7))
+    nb = knn_prefix(x, 6, chunk=128)
+    x32 = x.astype(np.float32)
+    for i in (0, 1, 4, 5, 6, 77, 499):
+        d = ((x32[:i + 1] - x32[i]) ** 2).sum(axis=1)
+        want = np.argsort(d, kind="stable")[:6]
+        got = nb[i][nb[i] >= 0]
+        assert set(got.tolist()) == set(want.tolist()) and got[0] == i
