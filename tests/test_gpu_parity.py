@@ -559,6 +559,64 @@ def test_batched_prm_on_the_device(fresh_world, torch_cuda):
             assert conn.connect(a.state, b.state) is not None or conn.connect(b.state, a.state) is not None
 
 
+@pytest.mark.parametrize("seed", [101, 102, 104, 106, 109, 110, 120])
+def test_random_mechanisms_and_scenes(fresh_world, seed, torch_cuda, tmp_path):
+    """Fuzz: random trees (3-10 links, mixed joint types, compound links) among random obstacles (all primitive kinds,
+    planes, margins): every entry point bit-exact against the oracle, through all three validity paths."""
+    import os
+    from numbotics_amd.physics import GraphChain
+    from numbotics_amd.robots import Arm
+    from random_scenes import random_urdf, random_obstacles
+    rng = np.random.default_rng(seed)
+    n_links = int(rng.integers(3, 11))
+    if seed == 120:
+        n_links = 19                                  # more than 16 robot primitives: the LDS broadphase serves it
+    chain = GraphChain.from_urdf(random_urdf(rng, n_links, str(tmp_path / "fuzz.urdf")))
+    if chain.dof == 0:
+        pytest.skip("all joints fixed")
+    arm = Arm(chain)
+    obs = random_obstacles(rng, int(rng.integers(1, 7)))
+    sm = arm.scene_model()
+    if sm.n_pairs == 0:
+        pytest.skip("no collision pairs")
+    orc = Oracle(sm)
+    lim = np.asarray(chain.joint_limits, dtype=np.float64)
+    lim = np.where(np.isfinite(lim), lim, np.sign(lim) * np.pi)
+    q = rng.uniform(lim[:, 0], lim[:, 1], (9000, chain.dof))
+    for thr in (0.0, float(rng.choice([0.02, -0.003]))):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref), f"two-kernel path, thr {thr}"
+        assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), f"fused path, thr {thr}"
+        os.environ["NBK_NO_REG_BROAD"] = "1"
+        try:
+            assert np.array_equal(arm.in_collision(q, thr), ref), f"LDS broadphase, thr {thr}"
+        finally:
+            del os.environ["NBK_NO_REG_BROAD"]
+    d, w, rows = arm.proximity_jacobians(q[:600])
+    dr, wr, rr = orc.proximity_jacobian(q[:600])
+    assert_bitwise(d, dr, "fuzz distances")
+    assert_bitwise(w, wr, "fuzz witnesses")
+    assert_bitwise(rows, rr, "fuzz jacobian rows")
+    dmin, idx = arm.closest_distance(q[:1500])
+    dref, iref = orc.closest(q[:1500])
+    assert_bitwise(dmin, dref, "fuzz closest")
+    assert np.array_equal(idx, iref)
+    _, dev = arm._scene_device()
+    s_, g_ = q[:150], q[150:300]
+    for mode in ("connect", "steer"):
+        ok, end, ns = dev.edge_validity(s_, g_, 0.03, 1.5, mode=mode)
+        okr, endr, nsr = orc.edge_validity(s_, g_, 0.03, 1.5, mode=mode)
+        assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
+        assert_bitwise(end, endr, "fuzz edge ends")
+    # kinematics of the last link
+    frame = [n for n in arm._kin.frames][-1]
+    orc_k = Oracle(arm._kin)
+    assert_bitwise(arm.forward_kinematics(q[:400], frame), orc_k.fk(q[:400], frame), "fuzz fk")
+    if len(arm._kin.frames[frame].path):
+        assert_bitwise(arm.jacobian(q[:400], frame), orc_k.jacobian(q[:400], frame), "fuzz jacobian")
+    assert len(obs) >= 1
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
