@@ -89,7 +89,8 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
-    bool margins_zero;        // every pair has mA = mB = 0: with threshold 0 the contact threshold tc is 0 for every pair
+    bool margins_zero;        // every pair that can reach GJK (no point core, not point/segment x point/segment) has mA = mB = 0:
+                              // with threshold 0 its contact threshold tc is exactly 0 and the boolean walk decides it
     // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
     void* ws;
     size_t ws_bytes;
@@ -1314,8 +1315,9 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
     if (mask_bytes != nullptr) mask_bytes[b] = 1;
 }
 
-// BOOL_ONLY: the host has established tc == 0 for every pair (threshold 0, no margins -- the reference's default
-// in_collision(q) call); only the boolean GJK state is kept, which removes the register spills of the general form.
+// BOOL_ONLY: the host has established tc == 0 for every pair that can reach GJK (threshold 0 and no margins on
+// box / cylinder / capsule-vs-solid pairs -- the reference's default in_collision(q) call on sharp shapes); only the
+// boolean GJK state is kept.
 // in-kernel phase timing of k_narrow (NBK_ABLATE bit 128): per working wave, cycles between stamps, summed
 __device__ unsigned long long g_narrow_prof[16];
 #define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
@@ -1419,7 +1421,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 int verdict;
                 if (m.dbg & 64) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[1][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[1][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; verdict = (acc == 12345.678) ? 1 : 0; }
                 else if (Bc.kind == K_PLANE) verdict = plane_collides(A, Bc, thr, cst[2]) ? 1 : 0;
-                else { tc = BOOL_ONLY ? 0.0 : (thr + cst[0]) + cst[1]; verdict = cores_collide_pre(A, Bc, tc); }
+                else { tc = (thr + cst[0]) + cst[1]; verdict = cores_collide_pre(A, Bc, tc); }
                 if (verdict == 1) mark_hit(b, mask_bits, mask_bytes);
                 pooled = verdict < 0;
             }
@@ -1433,7 +1435,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                     if (POOL_CAP >= NARROW_T || slot < POOL_CAP) pool_put<POOL_CAP>(pool, slot, A, Bc, tc, b);
                     else {
                         // pool full (more survivors in this chunk than the pool was sized for): decide in place
-                        const bool hit = (tc == 0.0) ? gjk_intersect(A, Bc) : gjk_collides(A, Bc, tc);
+                        const bool hit = (BOOL_ONLY || tc == 0.0) ? gjk_intersect(A, Bc) : gjk_collides(A, Bc, tc);
                         if (hit) mark_hit(b, mask_bits, mask_bytes);
                     }
                 }
@@ -2110,7 +2112,11 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         vp_cst[4 * i] = ca[4]; vp_cst[4 * i + 1] = cb[4];
         vp_cst[4 * i + 2] = host_bound_radius(ka, ca);
         vp_cst[4 * i + 3] = host_bound_radius(kb, cb);
-        if (kb != K_PLANE && (ca[4] != 0.0 || cb[4] != 0.0)) margins_zero = false;
+        {
+            const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;          // canonical order
+            const bool closed = k0 == K_POINT || ((k0 == K_POINT || k0 == K_SEG) && (k1 == K_POINT || k1 == K_SEG));
+            if (k1 != K_PLANE && !closed && (ca[4] != 0.0 || cb[4] != 0.0)) margins_zero = false;
+        }
     }
     for (int w = 0; w < W; ++w) { ws_center[3 * w] = ws_core[18 * w]; ws_center[3 * w + 1] = ws_core[18 * w + 1]; ws_center[3 * w + 2] = ws_core[18 * w + 2]; }
     std::vector<unsigned> frame_mask(J > 0 ? J : 1, 0u), rs_mask(S > 0 ? S : 1, 0u);

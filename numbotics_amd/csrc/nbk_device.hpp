@@ -566,21 +566,33 @@ NBK_DEV int gjkb_step(GjkBool& g, const Core& A, const Core& Bc) {
         sub3(g.p[0], a, ab);
         if (dot3(ab, ao) > 0.0) { copy3(a, g.p[1]); g.n = 2; tri_prod(ab, ao, g.d); }
         else { copy3(a, g.p[0]); g.n = 1; copy3(ao, g.d); }
-    } else if (g.n == 2) {
-        gjkb_triangle(g, g.p[0], g.p[1], a);
     } else {
-        double ab[3], ac[3], ad[3], abc[3], acd[3], adb[3];
-        const double ao[3] = {-a[0], -a[1], -a[2]};
-        const double dd[3] = {g.p[0][0], g.p[0][1], g.p[0][2]}, c[3] = {g.p[1][0], g.p[1][1], g.p[1][2]}, b[3] = {g.p[2][0], g.p[2][1], g.p[2][2]};
-        sub3(b, a, ab); sub3(c, a, ac); sub3(dd, a, ad);
-        cross3(ab, ac, abc); cross3(ac, ad, acd); cross3(ad, ab, adb);
-        const double sabc = dot3(abc, ad) > 0.0 ? -1.0 : 1.0;
-        const double sacd = dot3(acd, ab) > 0.0 ? -1.0 : 1.0;
-        const double sadb = dot3(adb, ac) > 0.0 ? -1.0 : 1.0;
-        if (sabc * dot3(abc, ao) > 0.0) gjkb_triangle(g, c, b, a);
-        else if (sacd * dot3(acd, ao) > 0.0) gjkb_triangle(g, dd, c, a);
-        else if (sadb * dot3(adb, ao) > 0.0) gjkb_triangle(g, b, dd, a);
-        else return 2;
+        // n == 2: triangle (p0, p1, a); n == 3: the face of the tetrahedron (dd, c, b, a) that sees the origin, tested in
+        // the order abc, acd, adb -- the face is picked with selects so that the triangle case is instantiated once
+        double x[3], y[3];
+        bool enclosed = false;
+        if (g.n == 2) { copy3(g.p[0], x); copy3(g.p[1], y); }
+        else {
+            double ab[3], ac[3], ad[3], abc[3], acd[3], adb[3];
+            const double ao[3] = {-a[0], -a[1], -a[2]};
+            const double dd[3] = {g.p[0][0], g.p[0][1], g.p[0][2]}, c[3] = {g.p[1][0], g.p[1][1], g.p[1][2]}, b[3] = {g.p[2][0], g.p[2][1], g.p[2][2]};
+            sub3(b, a, ab); sub3(c, a, ac); sub3(dd, a, ad);
+            cross3(ab, ac, abc); cross3(ac, ad, acd); cross3(ad, ab, adb);
+            const double sabc = dot3(abc, ad) > 0.0 ? -1.0 : 1.0;
+            const double sacd = dot3(acd, ab) > 0.0 ? -1.0 : 1.0;
+            const double sadb = dot3(adb, ac) > 0.0 ? -1.0 : 1.0;
+            const bool f0 = sabc * dot3(abc, ao) > 0.0;
+            const bool f1 = !f0 && sacd * dot3(acd, ao) > 0.0;
+            const bool f2 = !f0 && !f1 && sadb * dot3(adb, ao) > 0.0;
+            enclosed = !f0 && !f1 && !f2;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                x[e] = f0 ? c[e] : (f1 ? dd[e] : b[e]);
+                y[e] = f0 ? b[e] : (f1 ? c[e] : dd[e]);
+            }
+        }
+        if (enclosed) return 2;
+        gjkb_triangle(g, x, y, a);
     }
     if (dot3(g.d, g.d) == 0.0) return 2;
     return 0;
