@@ -59,6 +59,12 @@ struct DevModel {
     int n_plane_pairs, n_closed_pairs;   // class boundaries inside the sorted tables
     const int* rs_frame;          // [S] moving frame of each robot shape (frame order, non-decreasing)
     const unsigned* rs_mask;      // [S] joints on the path from the base to the shape's frame (bit k = joint k)
+    // float copies for the conservative float32 broadphase (k_broad_f32): [J][27] rot | [J][3] trans | [J][3] slide |
+    // base[12] | [S][3] shape centre offsets | [W][18] world cores; slack = f_eps * max(f_reach, largest |coordinate| of
+    // the configuration) covers the float32 error of the sweep 50 times over
+    const float* f_tab;
+    int f_trans, f_slide, f_base, f_tl, f_wc;
+    float f_eps, f_reach;
     const int4* vp_info;          // [P] canonical refs and their joint masks in one 16-byte record: ra, rb, mask(ra), mask(rb)
     int bq_count[4];              // pairs per broadphase category
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
@@ -1224,6 +1230,299 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
 }
 
+// ---- k_broad_f32<S>: the register broadphase in float32, conservative -----------------------------------------------
+// The broadphase only has to cull pairs that are certainly free; every survivor is decided exactly (float64) by
+// k_narrow, which repeats the bounding-sphere test of the predicate in float64 first.  So the sweep, the centres and
+// the tests run in float32 (twice the VALU rate, half the registers: 5+ waves per SIMD) with every comparison pushed
+// towards "survives" by a slack `e` that covers the float32 error of the sweep 50 times over:
+//   spheres  cull  iff |cA - cB|^2_f32 >= ((tc + rhoA + rhoB) + 2e)^2 (rounded up);
+//   planes   cull  iff hc_f32 - rhoA >= t + 2e;
+//   boxes    cull  iff d^2(c, box)_f32 >= ((tc + rho) + 2e)^2 (tc >= 0);  certified hit iff the centre is inside
+//            deeper than -tc by more than 2e (then it is inside in float64 as well).
+// Tables in LDS as in k_broad_reg (keys in float32, already including the static part of the slack).
+struct XfF { float R[9]; float t[3]; };
+
+// sin / cos to ~1e-7 absolute for |x| up to a few thousand radians (two-term Cody-Waite by pi/2, Taylor on [-pi/4, pi/4]);
+// the angle error of a float32 q (6e-8 |q|) is charged to the slack by the caller
+NBK_DEV void sincos_f(float x, float& s, float& c) {
+    const float k = __builtin_rintf(x * 0.63661977f);
+    float r = __builtin_fmaf(-k, 1.57079625f, x);
+    r = __builtin_fmaf(-k, 7.54978942e-8f, r);
+    const float r2 = r * r;
+    const float sp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.75573192e-6f, -1.98412698e-4f), 8.33333333e-3f), -1.66666667e-1f);
+    const float cp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.48015873e-5f, -1.38888889e-3f), 4.16666667e-2f), -0.5f);
+    const float sr = __builtin_fmaf(r * r2, sp, r);
+    const float cr = __builtin_fmaf(r2, cp, 1.0f);
+    const int n = (int)k & 3;
+    const float s0 = (n & 1) ? cr : sr;
+    const float c0 = (n & 1) ? sr : cr;
+    s = (n & 2) ? -s0 : s0;
+    c = ((n + 1) & 2) ? -c0 : c0;
+}
+
+NBK_DEV void joint_apply_f(const DevModel& m, int k, const XfF& P, float qk, XfF& o) {
+    const float* M = m.f_tab + 27 * k;
+    const float* toff = m.f_tab + m.f_trans + 3 * k;
+    const float* sl = m.f_tab + m.f_slide + 3 * k;
+    float s = 0.0f, c = 0.0f;
+    if (m.joint_type[k] == NBK_REVOLUTE) sincos_f(qk, s, c);
+    float L[9], tl[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L[e] = __builtin_fmaf(s, M[18 + e], __builtin_fmaf(-c, M[9 + e], M[e]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tl[i] = __builtin_fmaf(qk, sl[i], toff[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            o.R[3 * i + j] = __builtin_fmaf(P.R[3 * i + 2], L[6 + j], __builtin_fmaf(P.R[3 * i + 1], L[3 + j], P.R[3 * i] * L[j]));
+        o.t[i] = __builtin_fmaf(P.R[3 * i + 2], tl[2], __builtin_fmaf(P.R[3 * i + 1], tl[1], __builtin_fmaf(P.R[3 * i], tl[0], P.t[i])));
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
+                                                   uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+                                                   unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
+                                                   unsigned long long cap) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int nq = m.n_q;
+    const int W = m.n_wshapes;
+    double* lds_raw = lds;
+    const int qrows = (WAVE * nq * 8 >= BQ_CAP * 4) ? nq : (BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+    float* lds_fr = reinterpret_cast<float*>(lds_raw + WAVE * qrows);             // saved frames [12*slots][64] float
+    float* lds_rkey = lds_fr + WAVE * 12 * m.frame_slots;                           // [S*S] (rs + static slack), < 0 = no pair
+    float* lds_wkey = lds_rkey + S * S;                                             // [W*S]
+    float* lds_wtc = lds_wkey + W * S;                                              // [W*S] tc of (world box w, robot a)
+    int* lds_rp = reinterpret_cast<int*>(lds_wtc + W * S);                          // [S*S]
+    int* lds_wp = lds_rp + S * S;                                                   // [W*S]
+    unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
+    const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
+    if (es.map != nullptr) {
+        if (lane < rows_i) {
+            unsigned e;
+            const double t = edge_t(es, es.map[base + lane], e);
+            const double omt = 1.0 - t;
+            const double* sp = es.starts + (size_t)e * nq;
+            const double* gp = es.goals + (size_t)e * nq;
+            for (int j = 0; j < nq; ++j) { const double a = omt * sp[j]; const double bb = t * gp[j]; lds_raw[lane * nq + j] = a + bb; }
+        } else {
+            for (int j = 0; j < nq; ++j) lds_raw[lane * nq + j] = 0.0;
+        }
+    } else {
+        const int total = rows_i * nq;
+        const double* src = q + base * nq;
+        if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
+            const double2* s2 = reinterpret_cast<const double2*>(src);
+            double2* d2 = reinterpret_cast<double2*>(lds_raw);
+            for (int i = lane; i < total / 2; i += WAVE) d2[i] = s2[i];
+        } else {
+            for (int i = lane; i < total; i += WAVE) lds_raw[i] = src[i];
+            for (int i = total + lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.0;
+        }
+    }
+    // ---- per-wave tables: radius sums (not squared: the per-configuration slack is added before squaring) -------------------
+    for (int i = lane; i < S * S; i += WAVE) { lds_rkey[i] = -1.0f; lds_rp[i] = -1; }
+    for (int i = lane; i < W * S; i += WAVE) { lds_wkey[i] = -1.0f; lds_wtc[i] = 0.0f; lds_wp[i] = -1; }
+    __syncthreads();
+    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    const float up = 1.0f + 2.4e-7f;                       // one rounding up for every double -> float conversion of a bound
+    for (int j = lane; j < P; j += WAVE) {
+        const int* t = m.bq_tab + 4 * j;
+        const int a = t[0] / 3, p = t[2], cat = t[3];
+        const double* cst = m.vp_cst + 4 * p;
+        if (cat == 1) {
+            const int b = t[1] / 3;
+            const double tc = (thr + cst[0]) + cst[1];
+            const double rs = (tc + cst[2]) + cst[3];
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            lds_rkey[lo * S + hi] = rs > 0.0 ? (float)rs * up : -1.0f;
+            lds_rp[lo * S + hi] = p;
+        } else {
+            const int w = t[1];
+            float key;
+            if (cat == 0) { const double tt = thr + cst[0]; key = (float)tt + __builtin_fabsf((float)tt) * 2.4e-7f; }   // plane: t, rounded up
+            else {
+                const double tc = (thr + cst[0]) + cst[1];
+                const double rs = (tc + cst[2]) + cst[3];
+                key = rs > 0.0 ? (float)rs * up : -1.0f;
+                lds_wtc[w * S + a] = (float)tc;
+            }
+            lds_wkey[w * S + a] = key;
+            lds_wp[w * S + a] = p;
+        }
+    }
+    __syncthreads();
+    const bool active = lane < rows_i;
+    bool hit = false;
+    // ---- sweep in float32: centres into registers ---------------------------------------------------------------------------
+    float cx[S], cy[S], cz[S];
+    float rmax = m.f_reach, qabs = 0.0f;
+    {
+        XfF bpose;
+        const float* bp = m.f_tab + m.f_base;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { bpose.R[3 * i] = bp[4 * i]; bpose.R[3 * i + 1] = bp[4 * i + 1]; bpose.R[3 * i + 2] = bp[4 * i + 2]; bpose.t[i] = bp[4 * i + 3]; }
+        XfF T = bpose;
+        int kcur = -1;
+#pragma unroll
+        for (int sidx = 0; sidx < S; ++sidx) {
+            cx[sidx] = 0.0f; cy[sidx] = 0.0f; cz[sidx] = 0.0f;
+            if (sidx < m.n_rshapes) {
+                const int f = m.rs_frame[sidx];
+                while (kcur < f) {
+                    ++kcur;
+                    const int k = kcur;
+                    const int ld = m.joint_load[k];
+                    XfF Pf;
+                    if (ld == -2) Pf = T;
+                    else if (ld == -1) Pf = bpose;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) Pf.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) Pf.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
+                    }
+                    const float qk = (float)lds_raw[lane * nq + m.joint_qidx[k]];
+                    qabs += __builtin_fabsf(qk);
+                    joint_apply_f(m, k, Pf, qk, T);
+                    const int sv = m.joint_save[k];
+                    if (sv >= 0) {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) lds_fr[(sv * 12 + e) * WAVE + lane] = T.R[e];
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) lds_fr[(sv * 12 + 9 + e) * WAVE + lane] = T.t[e];
+                    }
+                }
+                const float* tl = m.f_tab + m.f_tl + 3 * sidx;
+                const XfF& F = f < 0 ? bpose : T;
+                float c[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) c[i] = __builtin_fmaf(F.R[3 * i + 2], tl[2], __builtin_fmaf(F.R[3 * i + 1], tl[1], __builtin_fmaf(F.R[3 * i], tl[0], F.t[i])));
+                cx[sidx] = c[0]; cy[sidx] = c[1]; cz[sidx] = c[2];
+                rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(__builtin_fabsf(c[0]), __builtin_fmaxf(__builtin_fabsf(c[1]), __builtin_fabsf(c[2]))));
+            }
+        }
+    }
+    // both centres are off by at most e = rmax * (f_eps + the angle error of the float32 joint values, 6e-8 |q| each, x4)
+    const float e2 = 2.0f * rmax * __builtin_fmaf(2.4e-7f, qabs, m.f_eps);
+    __syncthreads();            // the q slab is dead from here on: its LDS region becomes the item queue
+    int qn = 0;
+    if (m.bq_count[1] > 0) {
+#pragma unroll
+        for (int a = 0; a < S - 1; ++a) {
+            unsigned long long bits = 0ull;
+#pragma unroll
+            for (int b = a + 1; b < S; ++b) {
+                const float rs = lds_rkey[a * S + b];
+                const float r = rs + e2;
+                const float dx = cx[a] - cx[b], dy = cy[a] - cy[b], dz = cz[a] - cz[b];
+                const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                bits |= (rs >= 0.0f && dd < r * r * up) ? (1ull << b) : 0ull;
+            }
+            if (!active || hit) bits = 0ull;
+            while (true) {
+                const bool has = bits != 0ull;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+                if (bal == 0ull) break;
+                if (has) {
+                    const int bit = __builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    const unsigned p = (unsigned)lds_rp[a * S + bit];
+                    const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    lds_queue[pos] = (p << 6) | (unsigned)lane;
+                }
+                qn += __builtin_popcountll(bal);
+                if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            }
+        }
+    }
+    for (int w = 0; w < W; ++w) {
+        const float* wc = m.f_tab + m.f_wc + 18 * w;
+        const int wk = m.ws_kind[w];
+        unsigned long long bits = 0ull;
+        if (wk == K_PLANE) {
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (a < m.n_rshapes) {
+                    const float key = lds_wkey[w * S + a];
+                    const float rhoA = (float)m.rs_core[6 * a + 5] * up;
+                    const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    const float hc = __builtin_fmaf(dz, wc[11], __builtin_fmaf(dy, wc[10], dx * wc[9]));
+                    const bool cand = (lds_wp[w * S + a] >= 0) && !((hc - rhoA) >= key + e2);
+                    bits |= cand ? (1ull << a) : 0ull;
+                }
+            }
+        } else if (wk == K_BOX) {
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (a < m.n_rshapes) {
+                    const float rs = lds_wkey[w * S + a];
+                    const float tc = lds_wtc[w * S + a];
+                    const float rho = (float)m.rs_core[6 * a + 5] * up;
+                    const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    const float r = rs + e2;
+                    bool cand = rs >= 0.0f && dd < r * r * up;
+                    // midphase on the exact box (distance of the centre outside, depth inside) -- only when some lane of
+                    // the wave passed the sphere test: far (shape, box) combinations cost six instructions
+                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+                        float ex2 = 0.0f, g = 3.4e38f;
+                        bool inside = true;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float axj = __builtin_fabsf(__builtin_fmaf(dz, wc[5 + 3 * j], __builtin_fmaf(dy, wc[4 + 3 * j], dx * wc[3 + 3 * j])));
+                            const float exj = axj - wc[12 + j];
+                            if (exj > 0.0f) { inside = false; ex2 = __builtin_fmaf(exj, exj, ex2); }
+                            g = __builtin_fminf(g, wc[12 + j] - axj);
+                        }
+                        if (!inside) {
+                            // outside by more than the slack in every float64 reading: free when far enough (tc >= 0 only)
+                            const float rr = (tc + rho) + e2;
+                            if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                        } else if (cand && g > -tc + e2 && rs > e2 && dd * up < (rs - e2) * (rs - e2)) {
+                            hit = true;         // inside deeper than -tc, and inside the sphere test, in float64 as well: certain hit
+                        }
+                    }
+                    bits |= cand ? (1ull << a) : 0ull;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < S; ++a) {
+                if (a < m.n_rshapes) {
+                    const float rs = lds_wkey[w * S + a];
+                    const float r = rs + e2;
+                    const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    bits |= (rs >= 0.0f && dd < r * r * up) ? (1ull << a) : 0ull;
+                }
+            }
+        }
+        if (!active || hit || (m.dbg & 4)) bits = 0ull;
+        while (true) {
+            const bool has = bits != 0ull;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
+            if (bal == 0ull) break;
+            if (has) {
+                const int bit = __builtin_ctzll(bits);
+                bits &= bits - 1ull;
+                const unsigned p = (unsigned)lds_wp[w * S + bit];
+                const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                lds_queue[pos] = (p << 6) | (unsigned)lane;
+            }
+            qn += __builtin_popcountll(bal);
+            if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+        }
+    }
+    if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
+    const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
+    if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
+    if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+}
+
 // core of shape `ref` (robot: from the replayed frame T; world: table).  Everything here is per lane.
 NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
     if (ref >= 0) {
@@ -1421,7 +1720,15 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 int verdict;
                 if (m.dbg & 64) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[1][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[1][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; verdict = (acc == 12345.678) ? 1 : 0; }
                 else if (Bc.kind == K_PLANE) verdict = plane_collides(A, Bc, thr, cst[2]) ? 1 : 0;
-                else { tc = (thr + cst[0]) + cst[1]; verdict = cores_collide_pre(A, Bc, tc); }
+                else {
+                    // step 2 of the predicate in float64: the float32 broadphase only culled what is certainly free
+                    tc = (thr + cst[0]) + cst[1];
+                    const double rs = (tc + cst[2]) + cst[3];
+                    double dc[3];
+                    sub3(A.c, Bc.c, dc);
+                    if (!(rs > 0.0) || !(dot3(dc, dc) < rs * rs)) verdict = 0;
+                    else verdict = cores_collide_pre(A, Bc, tc);
+                }
                 if (verdict == 1) mark_hit(b, mask_bits, mask_bytes);
                 pooled = verdict < 0;
             }
@@ -2154,7 +2461,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     Blob B;
     nbk_model* M = new nbk_model();
     memset(&M->d, 0, sizeof(M->d));
-    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi; } o;
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi, ft; } o;
     o.jt = B.add(d->joint_type, sizeof(int) * J);
     o.jq = B.add(d->joint_qidx, sizeof(int) * J);
     o.jl = B.add(load.data(), sizeof(int) * J);
@@ -2187,6 +2494,46 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         vp_info[4 * i + 3] = rb >= 0 ? (int)rs_mask[rb] : 0;
     }
     o.vi = B.add(vp_info.data(), sizeof(int) * 4 * P);
+    // float32 tables + error slack of the conservative broadphase.  Position error of a float32 chain sweep is below
+    // (joints + 2) * 16 ulp(float) * reach; the slack is 50x that, never below 1e-4 of the reach.
+    std::vector<float> ftab;
+    int f_trans, f_slide, f_base, f_tl, f_wc;
+    double reach = 0.0;
+    {
+        for (int k = 0; k < J; ++k) for (int e = 0; e < 27; ++e) ftab.push_back((float)d->joint_rot[27 * k + e]);
+        f_trans = (int)ftab.size();
+        for (int k = 0; k < J; ++k) {
+            double n2 = 0.0;
+            for (int e = 0; e < 3; ++e) { ftab.push_back((float)d->joint_trans[3 * k + e]); n2 += d->joint_trans[3 * k + e] * d->joint_trans[3 * k + e]; }
+            reach += std::sqrt(n2);
+        }
+        f_slide = (int)ftab.size();
+        for (int k = 0; k < J; ++k) for (int e = 0; e < 3; ++e) ftab.push_back((float)d->joint_slide[3 * k + e]);
+        f_base = (int)ftab.size();
+        {
+            double n2 = 0.0;
+            for (int e = 0; e < 12; ++e) ftab.push_back((float)d->base_pose[e]);
+            for (int i = 0; i < 3; ++i) n2 += d->base_pose[4 * i + 3] * d->base_pose[4 * i + 3];
+            reach += std::sqrt(n2);
+        }
+        f_tl = (int)ftab.size();
+        double lmax = 0.0;
+        for (int i = 0; i < S; ++i) {
+            double n2 = 0.0;
+            for (int r = 0; r < 3; ++r) { const double v = rs_local[12 * i + 4 * r + 3]; ftab.push_back((float)v); n2 += v * v; }
+            if (std::sqrt(n2) > lmax) lmax = std::sqrt(n2);
+        }
+        reach += lmax;
+        f_wc = (int)ftab.size();
+        for (int w = 0; w < W; ++w) {
+            double n2 = 0.0;
+            for (int e = 0; e < 18; ++e) ftab.push_back((float)ws_core[18 * w + e]);
+            for (int e = 0; e < 3; ++e) n2 += ws_core[18 * w + e] * ws_core[18 * w + e];
+            if (std::sqrt(n2) > reach) reach = std::sqrt(n2);          // world coordinates enter the differences too
+        }
+        if (ftab.empty()) ftab.push_back(0.0f);
+    }
+    o.ft = B.add(ftab.data(), sizeof(float) * ftab.size());
     std::vector<int> rs_frame_v(S > 0 ? S : 1, -1);
     for (int i = 0; i < S; ++i) rs_frame_v[i] = d->rshape_frame[order[i]];
     o.rf = B.add(rs_frame_v.data(), sizeof(int) * S);
@@ -2229,6 +2576,15 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.n_plane_pairs = n_plane; m.n_closed_pairs = n_closed;
     m.rs_mask = reinterpret_cast<const unsigned*>(base + o.rm);
     m.vp_info = reinterpret_cast<const int4*>(base + o.vi);
+    m.f_tab = reinterpret_cast<const float*>(base + o.ft);
+    m.f_trans = f_trans; m.f_slide = f_slide; m.f_base = f_base; m.f_tl = f_tl; m.f_wc = f_wc;
+    // relative slack: 50 x the float32 error bound (joints + 2) * 16 ulp of a chain sweep; the kernel multiplies it by the
+    // larger of the static reach and the configuration's own largest coordinate (prismatic travel is unbounded here)
+    {
+        const double rel = 50.0 * (J + 2) * 16.0 * 5.96e-8;
+        m.f_eps = (float)(rel > 1e-4 ? rel : 1e-4);
+        m.f_reach = (float)(reach > 1e-3 ? reach : 1e-3);
+    }
     m.rs_frame = reinterpret_cast<const int*>(base + o.rf);
     m.bq_tab = reinterpret_cast<const int*>(base + o.bt);
     for (int c = 0; c < 4; ++c) { m.bq_count[c] = 0; }
@@ -2378,7 +2734,14 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         uint8_t* my = mask_bytes ? mask_bytes + b0 : nullptr;
         const int S = m->d.n_rshapes;
         const bool use_reg = S <= 16 && !getenv("NBK_NO_REG_BROAD");
-        if (use_reg && S <= 8)
+        static const bool f32 = !getenv("NBK_F64_BROAD");
+        if (use_reg && f32 && S <= 8)
+            hipLaunchKernelGGL(k_broad_f32<8>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 8), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+        else if (use_reg && f32 && S <= 12)
+            hipLaunchKernelGGL(k_broad_f32<12>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 12), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+        else if (use_reg && f32)
+            hipLaunchKernelGGL(k_broad_f32<16>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 16), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+        else if (use_reg && S <= 8)
             hipLaunchKernelGGL(k_broad_reg<8>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 8), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         else if (use_reg && S <= 12)
             hipLaunchKernelGGL(k_broad_reg<12>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 12), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
