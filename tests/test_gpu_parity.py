@@ -617,6 +617,102 @@ def test_random_mechanisms_and_scenes(fresh_world, seed, torch_cuda, tmp_path):
     assert len(obs) >= 1
 
 
+@pytest.mark.parametrize("scene", ["c2", "c3"])
+def test_contact_transitions_are_resolved_exactly(fresh_world, scene, torch_cuda):
+    """The float32 broadphase may only cull what is certainly free: sweep one joint in steps of 1e-10 rad across
+    collision / free transitions found by bisection on the oracle, and ask for the same mask bit for bit."""
+    arm, chain, obs = build_scene(scene)
+    orc = Oracle(arm.scene_model())
+    base = sample_q(chain, 3000, seed=77)
+    m0 = orc.validity(base, 0.0, nthreads=8)
+    rng = np.random.default_rng(7)
+    sweeps = []
+    for i in np.nonzero(m0)[0][:400]:
+        j = int(rng.integers(0, chain.dof))
+        lo, hi = base[i].copy(), base[i].copy()          # hi collides; look for a free value of joint j nearby
+        for step in (0.05, 0.2, 0.6):
+            lo[j] = base[i][j] + step
+            if not orc.validity(lo[None], 0.0)[0]:
+                break
+        else:
+            continue
+        for _ in range(60):                              # bisect the transition down to the last bits
+            mid = 0.5 * (lo + hi)
+            if orc.validity(mid[None], 0.0)[0]:
+                hi = mid
+            else:
+                lo = mid
+        fine = np.tile(hi, (400, 1))
+        fine[:, j] = hi[j] + (np.arange(400) - 200) * 1e-10
+        sweeps.append(fine)
+        if len(sweeps) == 24:
+            break
+    assert len(sweeps) >= 20
+    q = np.concatenate(sweeps)                           # 9 600 configurations: the two-kernel path
+    ref = orc.validity(q, 0.0, nthreads=8)
+    assert 0.2 < ref.mean() < 0.8
+    assert np.array_equal(arm.in_collision(q, 0.0), ref)
+    assert np.array_equal(arm.in_collision(q[:4000], 0.0), ref[:4000])          # fused path
+    for thr in (1e-7, -1e-7):
+        assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr, nthreads=8))
+
+
+def test_broadphase_boundary_on_sphere_pairs(fresh_world, torch_cuda):
+    """Sphere link against sphere obstacles: the shapes fill their bounding spheres, so the contact transition IS the
+    boundary of the broadphase's bounding-sphere test -- the place where a non-conservative float32 cull would show."""
+    from numbotics_amd.physics import GraphChain, Sphere
+    from numbotics_amd.robots import Arm
+    from numbotics_amd.utils import Shape
+    from conftest import URDF
+    chain = GraphChain.from_urdf(URDF)
+    arm = Arm(chain)
+    rng = np.random.default_rng(12)
+    ball_links = [l for l in chain._links if l._collision_shape.shape == Shape.SPHERE]
+    assert len(ball_links) == 1
+    obs = [Sphere(0.0, float(rng.uniform(0.05, 0.25)), position=rng.uniform(-0.7, 0.7, 3) + np.array([0.0, 0.0, 0.5])) for _ in range(10)]
+    for a, b in list(arm.self_collision_pairs()):
+        arm.remove_collision_pair(a, b)
+    for a, b in list(arm.collision_pairs()):
+        if a != ball_links[0] and b != ball_links[0]:
+            arm.remove_collision_pair(a, b)
+    sm = arm.scene_model()
+    assert sm.n_pairs == 10
+    orc = Oracle(sm)
+    base = sample_q(chain, 20000, seed=78)
+    m0 = orc.validity(base, 0.0, nthreads=8)
+    assert 0.01 < m0.mean() < 0.9
+    sweeps = []
+    for i in np.nonzero(m0)[0]:
+        j = int(rng.integers(0, 4))
+        lo, hi = base[i].copy(), base[i].copy()
+        for step in (0.3, 0.8, 1.5):
+            lo[j] = base[i][j] + step
+            if not orc.validity(lo[None], 0.0)[0]:
+                break
+        else:
+            continue
+        for _ in range(60):
+            mid = 0.5 * (lo + hi)
+            if orc.validity(mid[None], 0.0)[0]:
+                hi = mid
+            else:
+                lo = mid
+        fine = np.tile(hi, (400, 1))
+        fine[:, j] = hi[j] + (np.arange(400) - 200) * 1e-10
+        sweeps.append(fine)
+        if len(sweeps) == 30:
+            break
+    assert len(sweeps) >= 20
+    q = np.concatenate(sweeps)
+    ref = orc.validity(q, 0.0, nthreads=8)
+    assert 0.2 < ref.mean() < 0.8
+    assert np.array_equal(arm.in_collision(q, 0.0), ref)
+    d = arm.pair_distances(q)
+    assert np.abs(d.min(axis=1)).max() < 1e-7            # every configuration sits on the boundary of some pair
+    for thr in (1e-9, -1e-9, 1e-6):
+        assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr, nthreads=8))
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
