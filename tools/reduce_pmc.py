@@ -24,7 +24,7 @@ N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9
 VALU_F64_CYCLES = 4          # one wave64 float64 VALU instruction occupies its SIMD for 4 cycles (16 lanes/cycle)
 
-KERNELS = {"k_broad_reg": "nbk::k_broad_reg", "k_broad": "nbk::k_broad(", "k_narrow": "nbk::k_narrow",
+KERNELS = {"k_broad_f32": "nbk::k_broad_f32", "k_broad_reg": "nbk::k_broad_reg", "k_broad": "nbk::k_broad(", "k_narrow": "nbk::k_narrow",
            "k_fk": "nbk::k_fk", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
 
 
@@ -75,7 +75,7 @@ def main():
         fk, wk = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"])
         out["kernels"][k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": 2 * fk * 1024,
                              "write_bytes": wk * 1024, "hbm_bytes_corrected": 2 * fk * 1024 + wk * 1024}
-    step = [k for k in ("k_broad_reg", "k_broad", "k_narrow", "k_validity") if k in out["kernels"]]
+    step = [k for k in ("k_broad_f32", "k_broad_reg", "k_broad", "k_narrow", "k_validity") if k in out["kernels"]]
     out["validity_step_kernels"] = step
     out["validity_step_hbm_bytes"] = sum(out["kernels"][k]["hbm_bytes_corrected"] for k in step)
     if sq:
