@@ -189,7 +189,8 @@ def main():
                                f"{sm.n_pairs} primitive pairs ({sm.n_rshapes} robot shapes, {sm.n_wshapes} obstacle), "
                                f"{B} q per GPU per step, threshold 0, packed bit mask"
                                + (", RCCL all-gather of mask words" if world > 1 else ""),
-                   "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}"},
+                   "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
+                   "arithmetic": "every verdict is decided in float64 (bit-exact vs the CPU oracle); the broadphase culls in float32 with a slack that only lets it cull what float64 would"},
         "roofline": roofline, "fk_roofline": fk_roofline, "cpu_baseline": cpu,
         "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",
         "parity_sample": int(sl.size),
