@@ -713,6 +713,29 @@ def test_broadphase_boundary_on_sphere_pairs(fresh_world, torch_cuda):
         assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr, nthreads=8))
 
 
+def test_large_joint_values_stay_exact(fresh_world, torch_cuda):
+    """Angles of thousands of radians (continuous joints) and metres of prismatic travel: the float32 broadphase's slack
+    grows with |q| and with the configuration's extent, the masks stay those of the oracle."""
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    rng = np.random.default_rng(21)
+    q = sample_q(chain, 9000, seed=79)
+    q_big = q + 2.0 * np.pi * rng.integers(-500, 500, q.shape)              # same poses, |q| up to ~3000 rad
+    ref = orc.validity(q_big, 0.0, nthreads=8)
+    assert np.array_equal(arm.in_collision(q_big, 0.0), ref) and 0.02 < ref.mean() < 0.5
+    q_wild = q * rng.choice([1.0, 30.0, 1000.0], size=q.shape)
+    assert np.array_equal(arm.in_collision(q_wild, 0.0), orc.validity(q_wild, 0.0, nthreads=8))
+
+
+def test_large_prismatic_travel_stays_exact(fresh_world, torch_cuda):
+    arm2, chain2, obs2 = _tree_scene()
+    orc2 = Oracle(arm2.scene_model())
+    rng = np.random.default_rng(22)
+    q2 = sample_q(chain2, 9000, seed=80)
+    q2[:, ::2] *= rng.choice([1.0, 1.0, 40.0], size=q2[:, ::2].shape)       # joints pushed metres / radians past their limits
+    assert np.array_equal(arm2.in_collision(q2, 0.0), orc2.validity(q2, 0.0, nthreads=8))
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
