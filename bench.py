@@ -157,6 +157,23 @@ def main():
                    "frac": fk_gbs / HBM_PEAK_GBS, "traffic": fk_traffic, "kernel_ms": fk_ms, "algorithmic_bytes": fk_bytes,
                    "poses_per_s": (hi - lo) / (fk_ms * 1e-3), "algorithmic_bytes_per_config": 8.0 * chain.dof + 128.0}
 
+    # ---- every link pose from one sweep (56 + 128 L bytes per configuration) ----------------
+    TA, link_names = arm.forward_kinematics_all(q)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        TA, _ = arm.forward_kinematics_all(q)
+    e1.record()
+    torch.cuda.synchronize()
+    fa_ms = e0.elapsed_time(e1) / 10
+    L = len(link_names)
+    fa_bytes = (hi - lo) * (8.0 * chain.dof + 128.0 * L)
+    fk_all_roofline = {"bound": "hbm", "kernel": "k_fk_frames", "achieved": fa_bytes / (fa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": fa_bytes / (fa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": fa_ms,
+                       "algorithmic_bytes": fa_bytes, "link_frames": L, "poses_per_s": (hi - lo) * L / (fa_ms * 1e-3),
+                       "algorithmic_bytes_per_config": 8.0 * chain.dof + 128.0 * L}
+    del TA
+
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample ---------------------
     cpu = None
     if not args.no_cpu_baseline:
@@ -191,7 +208,7 @@ def main():
                                + (", RCCL all-gather of mask words" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
                    "arithmetic": "every verdict is decided in float64 (bit-exact vs the CPU oracle); the broadphase culls in float32 with a slack that only lets it cull what float64 would"},
-        "roofline": roofline, "fk_roofline": fk_roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "fk_roofline": fk_roofline, "fk_all_links_roofline": fk_all_roofline, "cpu_baseline": cpu,
         "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",
         "parity_sample": int(sl.size),
     }

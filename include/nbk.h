@@ -97,6 +97,20 @@ int32_t nbk_fk_batch(const nbk_model *m, const double *q, int64_t B, const int32
                      const double *local, const double *local_pose, double *T_out, void *stream);
 
 /*
+ * FK of many frames of every configuration in one sweep (additive: the reference computes one frame per call,
+ * numbotics/robots/arm.py:369-410; callers that need every link pose -- visualisation, proximity bookkeeping -- loop over
+ * the link names).  A frame set names each frame by the moving frame (joint index, -1 = base) it hangs off and its constant
+ * 3x4 local pose (trailing fixed joints, COM offset); host arrays, copied to the device once.
+ *   T_out (device) [B][n_frames][16], frame order as given.  Poses are bit-identical to nbk_fk_batch on the same frame.
+ */
+typedef struct nbk_frameset nbk_frameset;
+int32_t nbk_frameset_create(const nbk_model *m, int32_t n_frames, const int32_t *frame_joint, const double *frame_local,
+                            nbk_frameset **out);
+void nbk_frameset_destroy(nbk_frameset *fs);
+int32_t nbk_fk_frames_batch(const nbk_model *m, const nbk_frameset *fs, const double *q, int64_t B, double *T_out,
+                            void *stream);
+
+/*
  * Batched geometric Jacobian [v; w] of one frame.
  * Replaces nb_compute_jacobian (numbotics/robots/helpers.py:117-187) as called by Arm.jacobian
  * (numbotics/robots/arm.py:413-461).  mode 0: end pose = T*local; 1: T*local*pose[b] (local_pose);

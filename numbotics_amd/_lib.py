@@ -18,7 +18,7 @@ STATUS = {0: "NBK_OK", -1: "NBK_ERR_INVALID", -2: "NBK_ERR_NO_DEVICE", -3: "NBK_
 SYMBOLS = [
     "nbk_abi_version", "nbk_status_string", "nbk_last_error", "nbk_device_count",
     "nbk_model_create", "nbk_model_destroy", "nbk_model_num_pairs",
-    "nbk_fk_batch", "nbk_jacobian_batch", "nbk_ik_batch", "nbk_validity_batch", "nbk_validity_workspace_bytes",
+    "nbk_fk_batch", "nbk_frameset_create", "nbk_frameset_destroy", "nbk_fk_frames_batch", "nbk_jacobian_batch", "nbk_ik_batch", "nbk_validity_batch", "nbk_validity_workspace_bytes",
     "nbk_validity_batch_ws", "nbk_closest_batch",
     "nbk_pair_distances_batch", "nbk_proximity_jacobian_batch", "nbk_edge_validity_batch", "nbk_selftest_math",
     "nbk_fk_batch_host", "nbk_validity_batch_host",
@@ -67,6 +67,10 @@ def load():
     vp, i32, i64, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     lib.nbk_fk_batch.argtypes = [vp, vp, i64, vp, i32, vp, vp, vp, vp]
     lib.nbk_jacobian_batch.argtypes = [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]
+    lib.nbk_frameset_create.argtypes = [vp, i32, vp, vp, vp]
+    lib.nbk_frameset_destroy.argtypes = [vp]
+    lib.nbk_frameset_destroy.restype = None
+    lib.nbk_fk_frames_batch.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.nbk_ik_batch.argtypes = [vp, vp, vp, i64, vp, i32, vp, vp, f64, i32, i32, vp, vp, vp, vp, vp]
     lib.nbk_validity_batch.argtypes = [vp, vp, i64, f64, vp, vp, vp]
     lib.nbk_validity_workspace_bytes.argtypes = [vp, i64]

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/nbk.h"
@@ -442,6 +443,76 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- FK of many frames in one sweep (all link poses of a configuration) ---------------------------------------------
+// One tree sweep with the descriptor's load/save plan; after joint k the poses of the requested frames that hang off it
+// (fs_begin ranges, frames sorted by joint) are E = T_k * local_f, transposed through LDS (17-double rows, as k_fk) and
+// written as whole 128-byte lines to T_out[b][f_out][16].  56 + 128 n_frames bytes per configuration: HBM-bound.
+// LDS: q rows [n_q][64] | saved frames [12 slots][64] | transpose 64 x 17.
+__global__ __launch_bounds__(64) void k_fk_frames(DevModel m, const double* __restrict__ q, int64_t B, int n_frames,
+                                                   const int* __restrict__ fs_begin, const int* __restrict__ fs_out,
+                                                   const double* __restrict__ fs_local, double* __restrict__ T_out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    double* lds_q = lds;
+    double* lds_fr = lds_q + WAVE * m.n_q;
+    double* lds_t = lds_fr + WAVE * 12 * m.frame_slots;
+    stage_q(q, base, B, m.n_q, lds_t, lds_q, lane);         // the transpose area doubles as the raw q slab (n_q <= 17 or larger: sized by the host)
+    const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
+    Xf bpose;
+    xf_from12(m.base_pose, bpose);
+    Xf T = bpose;
+    for (int k = -1; k < m.n_joints; ++k) {
+        if (k >= 0) {
+            const int ld = m.joint_load[k];
+            Xf P;
+            if (ld == -2) P = T;
+            else if (ld == -1) P = bpose;
+            else {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) P.R[e] = lds_fr[(ld * 12 + e) * WAVE + lane];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) P.t[e] = lds_fr[(ld * 12 + 9 + e) * WAVE + lane];
+            }
+            joint_apply(m, k, P, lds_q[m.joint_qidx[k] * WAVE + lane], T);
+            const int sv = m.joint_save[k];
+            if (sv >= 0) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) lds_fr[(sv * 12 + e) * WAVE + lane] = T.R[e];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) lds_fr[(sv * 12 + 9 + e) * WAVE + lane] = T.t[e];
+            }
+        }
+        const int f0 = fs_begin[k + 1], f1 = fs_begin[k + 2];
+        for (int f = f0; f < f1; ++f) {
+            Xf loc, E;
+            xf_from12(fs_local + 12 * f, loc);
+            if (k < 0) xf_mul(bpose, loc.R, loc.t, E); else xf_mul(T, loc.R, loc.t, E);
+            __syncthreads();                                   // the previous frame's rows have been read
+            double* row = lds_t + lane * 17;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                row[4 * i] = E.R[3 * i]; row[4 * i + 1] = E.R[3 * i + 1]; row[4 * i + 2] = E.R[3 * i + 2];
+                row[4 * i + 3] = E.t[i];
+            }
+            row[12] = 0.0; row[13] = 0.0; row[14] = 0.0; row[15] = 1.0;
+            __syncthreads();
+            const int fo = fs_out[f];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const int g = lane + WAVE * kk;                // double2 index inside this frame's 64 x 16 slab
+                const int r = g >> 3, c2 = (g & 7) * 2;
+                if (r < rows) {
+                    double2 v;
+                    v.x = lds_t[r * 17 + c2];
+                    v.y = lds_t[r * 17 + c2 + 1];
+                    *reinterpret_cast<double2*>(T_out + ((size_t)(base + r) * n_frames + fo) * 16 + c2) = v;
+                }
+            }
+        }
     }
 }
 
@@ -2744,6 +2815,63 @@ int32_t nbk_fk_batch(const nbk_model* m, const double* q, int64_t B, const int32
     if (B == 0) return NBK_OK;
     const size_t lds = sizeof(double) * WAVE * ((size_t)(m->n_q > 17 ? m->n_q : 17));
     hipLaunchKernelGGL(k_fk, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, local_pose, T_out);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+// ---- frame sets: FK of many frames per configuration --------------------------------------------------------------
+struct nbk_frameset {
+    int n;
+    void* blob;                 // begin[J+2] | out[n] | local[n][12]
+    const int* begin;
+    const int* out;
+    const double* local;
+};
+
+int32_t nbk_frameset_create(const nbk_model* m, int32_t n_frames, const int32_t* frame_joint, const double* frame_local,
+                            nbk_frameset** out) {
+    if (m == nullptr || out == nullptr || n_frames < 1 || n_frames > 4096 || frame_joint == nullptr || frame_local == nullptr) return NBK_ERR_INVALID;
+    const int J = m->n_joints;
+    for (int f = 0; f < n_frames; ++f) if (frame_joint[f] < -1 || frame_joint[f] >= J) return NBK_ERR_INVALID;
+    std::vector<int> order(n_frames), begin(J + 2, 0), outv(n_frames);
+    for (int f = 0; f < n_frames; ++f) order[f] = f;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return frame_joint[a] < frame_joint[b]; });
+    for (int f = 0; f < n_frames; ++f) begin[frame_joint[f] + 2] += 1;
+    for (int k = 1; k < J + 2; ++k) begin[k] += begin[k - 1];
+    std::vector<double> local(12 * (size_t)n_frames);
+    for (int i = 0; i < n_frames; ++i) { outv[i] = order[i]; memcpy(&local[12 * i], frame_local + 12 * order[i], 12 * sizeof(double)); }
+    Blob Bb;
+    const size_t ob = Bb.add(begin.data(), sizeof(int) * (J + 2));
+    const size_t oo = Bb.add(outv.data(), sizeof(int) * n_frames);
+    const size_t ol = Bb.add(local.data(), sizeof(double) * 12 * n_frames);
+    nbk_frameset* fs = new nbk_frameset();
+    fs->n = n_frames; fs->blob = nullptr;
+    hipError_t e = hipMalloc(&fs->blob, Bb.bytes.size());
+    if (e != hipSuccess) { delete fs; hip_fail(e, "hipMalloc(frameset)"); return NBK_ERR_ALLOC; }
+    e = hipMemcpy(fs->blob, Bb.bytes.data(), Bb.bytes.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(fs->blob); delete fs; return hip_fail(e, "hipMemcpy(frameset)"); }
+    const char* b = static_cast<const char*>(fs->blob);
+    fs->begin = reinterpret_cast<const int*>(b + ob);
+    fs->out = reinterpret_cast<const int*>(b + oo);
+    fs->local = reinterpret_cast<const double*>(b + ol);
+    *out = fs;
+    return NBK_OK;
+}
+
+void nbk_frameset_destroy(nbk_frameset* fs) {
+    if (fs == nullptr) return;
+    if (fs->blob) (void)hipFree(fs->blob);
+    delete fs;
+}
+
+int32_t nbk_fk_frames_batch(const nbk_model* m, const nbk_frameset* fs, const double* q, int64_t B, double* T_out, void* stream) {
+    if (m == nullptr || fs == nullptr || B < 0 || (B > 0 && (q == nullptr || T_out == nullptr))) return NBK_ERR_INVALID;
+    if (B == 0) return NBK_OK;
+    const size_t tr = (size_t)(m->n_q > 17 ? m->n_q : 17);
+    const size_t lds = sizeof(double) * WAVE * ((size_t)m->n_q + 12 * (size_t)m->d.frame_slots + tr);
+    if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_fk_frames, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, q, B, fs->n, fs->begin, fs->out,
+                       fs->local, T_out);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }

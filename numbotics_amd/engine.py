@@ -96,6 +96,11 @@ class DeviceModel:
 
     def __del__(self):
         h = getattr(self, "_h", None)
+        for fs in getattr(self, "_framesets", {}).values():
+            try:
+                self._lib.nbk_frameset_destroy(fs)
+            except Exception:
+                pass
         if h:
             try:
                 self._lib.nbk_model_destroy(h)
@@ -127,6 +132,33 @@ class DeviceModel:
         _lib.check(self._lib.nbk_fk_batch(self._h, qs.t.data_ptr(), qs.B, path.ctypes.data, len(path),
                                           local.ctypes.data, None if lp is None else lp.t.data_ptr(),
                                           out.data_ptr(), self._stream()), "nbk_fk_batch")
+        return qs.out(out)
+
+    def fk_frames(self, q, frames, extra_locals=None):
+        """Poses of several frames per configuration in one sweep: (B, len(frames), 4, 4), bit-identical to ``fk`` per frame.
+        ``extra_locals``: optional {frame: 4x4} right factors (e.g. COM offsets)."""
+        torch = _require_gpu()
+        qs = _Staged(q, self.n_q)
+        frames = list(frames)
+        ex = extra_locals or {}
+        key = (tuple(frames), tuple(sorted((k, np.asarray(v, dtype=np.float64).tobytes()) for k, v in ex.items())))
+        cache = self.__dict__.setdefault("_framesets", {})
+        fs = cache.get(key)
+        if fs is None:
+            joints = np.empty((len(frames),), dtype=np.int32)
+            locs = np.empty((len(frames), 12), dtype=np.float64)
+            for i, f in enumerate(frames):
+                fr = self.kin.frames[f]
+                local = fr.local if f not in ex else fr.local @ np.asarray(ex[f], dtype=np.float64)
+                joints[i] = fr.joint
+                locs[i] = np.ascontiguousarray(local[:3, :4]).reshape(12)
+            h = C.c_void_p()
+            _lib.check(self._lib.nbk_frameset_create(self._h, len(frames), joints.ctypes.data, locs.ctypes.data, C.byref(h)),
+                       "nbk_frameset_create")
+            fs = cache[key] = h
+        out = torch.empty((qs.B, len(frames), 4, 4), dtype=torch.float64, device=qs.device)
+        _lib.check(self._lib.nbk_fk_frames_batch(self._h, fs, qs.t.data_ptr(), qs.B, out.data_ptr(), self._stream()),
+                   "nbk_fk_frames_batch")
         return qs.out(out)
 
     def jacobian(self, q, frame, extra_local=None, local_pose=None, global_pose=None):

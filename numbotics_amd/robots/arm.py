@@ -310,6 +310,23 @@ class Arm(Robot):
             return T[0]
         return T.reshape(*shape[:-1], 4, 4)
 
+    def forward_kinematics_all(self, q, frames=None, use_com: bool = False):
+        """Poses of many links in one launch (additive; upstream loops ``forward_kinematics`` over the link names):
+        ``(..., dof)`` -> ``(..., L, 4, 4)`` and the list of frame names (default: every link of the chain, chain order).
+        Each pose is bit-identical to ``forward_kinematics(q, name, use_com)``."""
+        if q.shape[-1] != self.dof:
+            raise ValueError(f"q must have {self.dof} elements")
+        names = list(self._kin.frames.keys()) if frames is None else list(frames)
+        for f in names:
+            if f not in self._kin.frames:
+                raise ValueError(f"Frame {f} not found in chain")
+        extra = {f: self._links_from_nodes[f]._offset for f in names} if use_com else None
+        shape = tuple(q.shape)
+        T = self._kin_device().fk_frames(q.reshape(-1, self.dof), names, extra_locals=extra)
+        if len(shape) == 1:
+            return T[0], names
+        return T.reshape(*shape[:-1], len(names), 4, 4), names
+
     def jacobian(self, q, frame: str, use_com: bool = False, local_pose=None, global_pose=False):
         self._check_frame_q(q, frame)
         if global_pose is False:          # upstream's default crashes on `.shape` (App. A Q2)

@@ -736,6 +736,34 @@ def test_large_prismatic_travel_stays_exact(fresh_world, torch_cuda):
     assert np.array_equal(arm2.in_collision(q2, 0.0), orc2.validity(q2, 0.0, nthreads=8))
 
 
+@pytest.mark.parametrize("robot", ["kinova", "tree"])
+def test_fk_of_all_links_in_one_sweep(fresh_world, robot, torch_cuda):
+    """nbk_fk_frames_batch: every link pose of every configuration from one tree sweep, bit-identical to the per-frame
+    kernel and to the oracle."""
+    if robot == "kinova":
+        arm, chain, obs = build_scene("c1")
+    else:
+        arm, chain, obs = _tree_scene()
+    orc = Oracle(arm._kin)
+    q = sample_q(chain, 3000, seed=90)
+    T, names = arm.forward_kinematics_all(q)
+    assert T.shape == (3000, len(names), 4, 4) and len(names) == len(arm._kin.frames) >= 8
+    for i, f in enumerate(names):
+        assert_bitwise(T[:, i], orc.fk(q, f), f"all-links fk {f}")
+        assert_bitwise(T[:64, i], arm.forward_kinematics(q[:64], f), f"all-links vs per-frame {f}")
+    sub = [names[-1], names[0], names[3]]
+    Ts, n2 = arm.forward_kinematics_all(q[:100], frames=sub, use_com=True)
+    assert n2 == sub
+    for i, f in enumerate(sub):
+        assert_bitwise(Ts[:, i], arm.forward_kinematics(q[:100], f, use_com=True), f"subset {f}")
+    T1, _ = arm.forward_kinematics_all(q[0])
+    assert T1.shape == (len(names), 4, 4) and np.array_equal(T1, T[0])
+    Tt, _ = arm.forward_kinematics_all(torch_cuda.from_numpy(q[:130]).cuda().reshape(2, 65, chain.dof))
+    assert Tt.is_cuda and tuple(Tt.shape) == (2, 65, len(names), 4, 4) and np.array_equal(Tt.cpu().numpy().reshape(130, -1), T[:130].reshape(130, -1))
+    with pytest.raises(ValueError):
+        arm.forward_kinematics_all(q, frames=["nope"])
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""

@@ -23,3 +23,13 @@ for _ in range(20): J = arm.jacobian(q, 'tool_frame')
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)/20
 print('jacobian ms %.4f'%ms, 'GB/s %.0f'%(B*392/ms/1e6))
+names = list(arm._kin.frames.keys())
+for _ in range(3): arm.forward_kinematics_all(q)
+torch.cuda.synchronize()
+e0,e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): TA, _n = arm.forward_kinematics_all(q)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)/10
+L = len(names)
+print('all %d link poses ms %.4f'%(L, ms), 'GB/s %.0f'%(B*(56+128*L)/ms/1e6), 'poses/s %.3e'%(B*L/ms*1e3))
