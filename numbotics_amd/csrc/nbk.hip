@@ -970,6 +970,57 @@ __global__ void k_zero_counters(unsigned long long* __restrict__ q_count) {
     q_count[threadIdx.x * CNT_STRIDE] = 0ull;
 }
 
+// Per-call tables of the float32 broadphase, built once per launch sequence by one workgroup (instead of by every wave
+// into LDS) and read by k_broad_f32 through scalar loads: everything in them is uniform over the launch.
+//   rkey[16*16] float  radius sum (rounded up) of robot-robot slot (a,b), a < b; < 0 = not a pair
+//   rp  [16*16] int    sorted pair index of the slot
+//   wkey[W*16], wtc[W*16] float, wp[W*16] int   the same for (world w, robot a); planes: key = t rounded up
+//   rho [16]    float  bounding radius of robot shape a, rounded up
+NBK_DEV size_t ftab_entries(int W) { return 2 * 256 + 3 * (size_t)W * 16 + 16; }
+
+__global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, unsigned long long* __restrict__ q_count, float* __restrict__ tab) {
+    const int t = threadIdx.x;
+    const int W = m.n_wshapes;
+    q_count[t * CNT_STRIDE] = 0ull;
+    float* rkey = tab;
+    int* rp = reinterpret_cast<int*>(tab + 256);
+    float* wkey = tab + 512;
+    float* wtc = wkey + (size_t)W * 16;
+    int* wp = reinterpret_cast<int*>(wtc + (size_t)W * 16);
+    float* rho = reinterpret_cast<float*>(wp + (size_t)W * 16);
+    const float up = 1.0f + 2.4e-7f;
+    rkey[t] = -1.0f; rp[t] = -1;
+    for (int i = t; i < W * 16; i += 256) { wkey[i] = -1.0f; wtc[i] = 0.0f; wp[i] = -1; }
+    if (t < 16) rho[t] = t < m.n_rshapes ? (float)m.rs_core[6 * t + 5] * up : 0.0f;
+    __syncthreads();
+    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    for (int j = t; j < P; j += 256) {
+        const int* bt = m.bq_tab + 4 * j;
+        const int a = bt[0] / 3, p = bt[2], cat = bt[3];
+        const double* cst = m.vp_cst + 4 * p;
+        if (cat == 1) {
+            const int b = bt[1] / 3;
+            const double tc = (thr + cst[0]) + cst[1];
+            const double rs = (tc + cst[2]) + cst[3];
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            rkey[lo * 16 + hi] = rs > 0.0 ? (float)rs * up : -1.0f;
+            rp[lo * 16 + hi] = p;
+        } else {
+            const int w = bt[1];
+            float key;
+            if (cat == 0) { const double tt = thr + cst[0]; key = (float)tt + __builtin_fabsf((float)tt) * 2.4e-7f; }
+            else {
+                const double tc = (thr + cst[0]) + cst[1];
+                const double rs = (tc + cst[2]) + cst[3];
+                key = rs > 0.0 ? (float)rs * up : -1.0f;
+                wtc[w * 16 + a] = (float)tc;
+            }
+            wkey[w * 16 + a] = key;
+            wp[w * 16 + a] = p;
+        }
+    }
+}
+
 // LDS: raw q slab [64*n_q] | saved frames [12*slots][64] | centres [3*S][64] | pair constants [P][4] |
 //      world cores [W][18] | queue [BQ_CAP] u32.
 // Lane = configuration throughout.  Everything a pair needs that does not depend on the configuration
@@ -1458,7 +1509,7 @@ template <int S>
 __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                    uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                                                    unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
-                                                   unsigned long long cap) {
+                                                   unsigned long long cap, const float* __restrict__ tab) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
@@ -1467,12 +1518,15 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
     double* lds_raw = lds;
     const int qrows = (WAVE * nq * 8 >= BQ_CAP * 4) ? nq : (BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
     float* lds_fr = reinterpret_cast<float*>(lds_raw + WAVE * qrows);             // saved frames [12*slots][64] float
-    float* lds_rkey = lds_fr + WAVE * 12 * m.frame_slots;                           // [S*S] (rs + static slack), < 0 = no pair
-    float* lds_wkey = lds_rkey + S * S;                                             // [W*S]
-    float* lds_wtc = lds_wkey + W * S;                                              // [W*S] tc of (world box w, robot a)
-    int* lds_rp = reinterpret_cast<int*>(lds_wtc + W * S);                          // [S*S]
-    int* lds_wp = lds_rp + S * S;                                                   // [W*S]
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
+    // launch-uniform tables (k_prepare_f32): scalar loads
+    const float* tab_rkey = tab;
+    const int* tab_rp = reinterpret_cast<const int*>(tab + 256);
+    const float* tab_wkey = tab + 512;
+    const float* tab_wtc = tab_wkey + (size_t)W * 16;
+    const int* tab_wp = reinterpret_cast<const int*>(tab_wtc + (size_t)W * 16);
+    const float* tab_rho = reinterpret_cast<const float*>(tab_wp + (size_t)W * 16);
+    const float up = 1.0f + 2.4e-7f;
     const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
     if (es.map != nullptr) {
         if (lane < rows_i) {
@@ -1495,37 +1549,6 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
         } else {
             for (int i = lane; i < total; i += WAVE) lds_raw[i] = src[i];
             for (int i = total + lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.0;
-        }
-    }
-    // ---- per-wave tables: radius sums (not squared: the per-configuration slack is added before squaring) -------------------
-    for (int i = lane; i < S * S; i += WAVE) { lds_rkey[i] = -1.0f; lds_rp[i] = -1; }
-    for (int i = lane; i < W * S; i += WAVE) { lds_wkey[i] = -1.0f; lds_wtc[i] = 0.0f; lds_wp[i] = -1; }
-    __syncthreads();
-    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
-    const float up = 1.0f + 2.4e-7f;                       // one rounding up for every double -> float conversion of a bound
-    for (int j = lane; j < P; j += WAVE) {
-        const int* t = m.bq_tab + 4 * j;
-        const int a = t[0] / 3, p = t[2], cat = t[3];
-        const double* cst = m.vp_cst + 4 * p;
-        if (cat == 1) {
-            const int b = t[1] / 3;
-            const double tc = (thr + cst[0]) + cst[1];
-            const double rs = (tc + cst[2]) + cst[3];
-            const int lo = a < b ? a : b, hi = a < b ? b : a;
-            lds_rkey[lo * S + hi] = rs > 0.0 ? (float)rs * up : -1.0f;
-            lds_rp[lo * S + hi] = p;
-        } else {
-            const int w = t[1];
-            float key;
-            if (cat == 0) { const double tt = thr + cst[0]; key = (float)tt + __builtin_fabsf((float)tt) * 2.4e-7f; }   // plane: t, rounded up
-            else {
-                const double tc = (thr + cst[0]) + cst[1];
-                const double rs = (tc + cst[2]) + cst[3];
-                key = rs > 0.0 ? (float)rs * up : -1.0f;
-                lds_wtc[w * S + a] = (float)tc;
-            }
-            lds_wkey[w * S + a] = key;
-            lds_wp[w * S + a] = p;
         }
     }
     __syncthreads();
@@ -1590,7 +1613,7 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
             unsigned long long bits = 0ull;
 #pragma unroll
             for (int b = a + 1; b < S; ++b) {
-                const float rs = lds_rkey[a * S + b];
+                const float rs = tab_rkey[a * 16 + b];
                 const float r = rs + e2;
                 const float dx = cx[a] - cx[b], dy = cy[a] - cy[b], dz = cz[a] - cz[b];
                 const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -1604,7 +1627,7 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
                 if (has) {
                     const int bit = __builtin_ctzll(bits);
                     bits &= bits - 1ull;
-                    const unsigned p = (unsigned)lds_rp[a * S + bit];
+                    const unsigned p = (unsigned)tab_rp[a * 16 + bit];
                     const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                     lds_queue[pos] = (p << 6) | (unsigned)lane;
                 }
@@ -1621,11 +1644,11 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
 #pragma unroll
             for (int a = 0; a < S; ++a) {
                 if (a < m.n_rshapes) {
-                    const float key = lds_wkey[w * S + a];
-                    const float rhoA = (float)m.rs_core[6 * a + 5] * up;
+                    const float key = tab_wkey[w * 16 + a];
+                    const float rhoA = tab_rho[a];
                     const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
                     const float hc = __builtin_fmaf(dz, wc[11], __builtin_fmaf(dy, wc[10], dx * wc[9]));
-                    const bool cand = (lds_wp[w * S + a] >= 0) && !((hc - rhoA) >= key + e2);
+                    const bool cand = (tab_wp[w * 16 + a] >= 0) && !((hc - rhoA) >= key + e2);
                     bits |= cand ? (1ull << a) : 0ull;
                 }
             }
@@ -1633,9 +1656,9 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
 #pragma unroll
             for (int a = 0; a < S; ++a) {
                 if (a < m.n_rshapes) {
-                    const float rs = lds_wkey[w * S + a];
-                    const float tc = lds_wtc[w * S + a];
-                    const float rho = (float)m.rs_core[6 * a + 5] * up;
+                    const float rs = tab_wkey[w * 16 + a];
+                    const float tc = tab_wtc[w * 16 + a];
+                    const float rho = tab_rho[a];
                     const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
                     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const float r = rs + e2;
@@ -1667,7 +1690,7 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
 #pragma unroll
             for (int a = 0; a < S; ++a) {
                 if (a < m.n_rshapes) {
-                    const float rs = lds_wkey[w * S + a];
+                    const float rs = tab_wkey[w * 16 + a];
                     const float r = rs + e2;
                     const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
                     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
@@ -1683,7 +1706,7 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
             if (has) {
                 const int bit = __builtin_ctzll(bits);
                 bits &= bits - 1ull;
-                const unsigned p = (unsigned)lds_wp[w * S + bit];
+                const unsigned p = (unsigned)tab_wp[w * 16 + bit];
                 const int pos = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
                 lds_queue[pos] = (p << 6) | (unsigned)lane;
             }
@@ -2931,7 +2954,10 @@ static inline size_t collide_lds(const nbk_model* m) {
 // ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
 static const int64_t TWO_KERNEL_MIN_B = 8192;
 static const size_t WS_MAX_BYTES = size_t(1) << 30;
-static const size_t WS_HEADER = NSUB * CNT_STRIDE * 8;        // NSUB counters, one cache line each
+static const size_t WS_COUNTERS = NSUB * CNT_STRIDE * 8;      // NSUB counters, one cache line each
+static inline size_t ws_header(const nbk_model* m) {           // counters | per-call float32 broadphase tables
+    return (WS_COUNTERS + 4 * (2 * 256 + 3 * (size_t)m->d.n_wshapes * 16 + 16) + 255) & ~size_t(255);
+}
 
 static inline size_t broad_lds(const nbk_model* m) {
     const size_t qrows = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
@@ -2941,7 +2967,7 @@ static inline size_t broad_lds(const nbk_model* m) {
 // configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
 static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
     const int64_t P = m->n_pairs > 0 ? m->n_pairs : 1;
-    int64_t t = (int64_t)((WS_MAX_BYTES - WS_HEADER) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
+    int64_t t = (int64_t)((WS_MAX_BYTES - ws_header(m)) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
     t = (t / WAVE) * WAVE;
     if (t < WAVE) t = WAVE;
     return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
@@ -2958,7 +2984,7 @@ static inline size_t broad_reg_lds(const nbk_model* m, int S) {
 static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                                  uint8_t* mask_bytes, void* workspace, hipStream_t st) {
     unsigned long long* count = static_cast<unsigned long long*>(workspace);
-    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + WS_HEADER);
+    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_header(m));
     const int64_t tile = tile_configs(m, B);
     for (int64_t b0 = 0; b0 < B; b0 += tile) {
         const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
@@ -2967,7 +2993,6 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         const unsigned long long cap_sub = (unsigned long long)((nblk + NSUB - 1) / NSUB) * WAVE * (unsigned long long)m->n_pairs;
         EdgeSrc es_tile = es;
         if (es.map != nullptr) es_tile.map = es.map + b0;
-        hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count);
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
         const double* qt = q ? q + b0 * m->n_q : nullptr;
         uint64_t* mb = mask_bits ? mask_bits + b0 / 64 : nullptr;
@@ -2975,12 +3000,20 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         const int S = m->d.n_rshapes;
         const bool use_reg = S <= 16 && !getenv("NBK_NO_REG_BROAD");
         static const bool f32 = !getenv("NBK_F64_BROAD");
+        float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
+        // LDS of the float32 kernel: q slab (later the item queue) + saved frames
+        const size_t qrows_f = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+        const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16;
+        if (use_reg && f32)
+            hipLaunchKernelGGL(k_prepare_f32, dim3(1), dim3(NSUB), 0, st, m->d, threshold, count, ftab);      // clears the counters too
+        else
+            hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count);
         if (use_reg && f32 && S <= 8)
-            hipLaunchKernelGGL(k_broad_f32<8>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 8), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+            hipLaunchKernelGGL(k_broad_f32<8>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
         else if (use_reg && f32 && S <= 12)
-            hipLaunchKernelGGL(k_broad_f32<12>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 12), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+            hipLaunchKernelGGL(k_broad_f32<12>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
         else if (use_reg && f32)
-            hipLaunchKernelGGL(k_broad_f32<16>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 16), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
+            hipLaunchKernelGGL(k_broad_f32<16>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
         else if (use_reg && S <= 8)
             hipLaunchKernelGGL(k_broad_reg<8>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 8), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         else if (use_reg && S <= 12)
@@ -3002,7 +3035,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
 
 static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
     const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
-    return (int64_t)WS_HEADER + 8 * (int64_t)NSUB * ((nblk + NSUB - 1) / NSUB) * WAVE * (int64_t)(m->n_pairs > 0 ? m->n_pairs : 1);
+    return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * ((nblk + NSUB - 1) / NSUB) * WAVE * (int64_t)(m->n_pairs > 0 ? m->n_pairs : 1);
 }
 
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
