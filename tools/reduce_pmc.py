@@ -25,7 +25,7 @@ CLOCK_HZ = 2.4e9
 VALU_F64_CYCLES = 4          # one wave64 float64 VALU instruction occupies its SIMD for 4 cycles (16 lanes/cycle)
 
 KERNELS = {"k_broad_f32": "nbk::k_broad_f32", "k_broad_reg": "nbk::k_broad_reg", "k_broad": "nbk::k_broad(", "k_narrow": "nbk::k_narrow",
-           "k_fk": "nbk::k_fk", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
+           "k_fk_frames": "nbk::k_fk_frames", "k_fk": "nbk::k_fk(", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
 
 
 def short(name):
