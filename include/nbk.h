@@ -199,6 +199,16 @@ int32_t nbk_edge_validity_batch(const nbk_model *m, const double *starts, const 
                                 int32_t mode, double threshold, uint8_t *valid, double *end,
                                 int32_t *n_samples, void *stream);
 
+/*
+ * Exact k nearest neighbours of every point among the points inserted before it (itself included): the neighbour lists
+ * an insert-then-query loop over the reference's flat L2 index yields (numbotics/math/geometry/nearest_neighbors.py:6-85,
+ * numbotics/planning/sampling_based/graph.py:165-178; faiss.IndexFlatL2 is a third-party dependency: tie-breaking and
+ * its float32 summation order are unpinned).  points (device) [N][dim] float32, k <= 64;
+ * out_idx (device) [N][k] int32, ascending by (distance, index), -1 padded for the first rows.
+ * distance = sum_c (x_c - y_c)^2 accumulated in dimension order with separate float32 roundings.
+ */
+int32_t nbk_knn_prefix(const float *points, int32_t n_points, int32_t dim, int32_t k, int32_t *out_idx, void *stream);
+
 /* Arithmetic-contract self test: elementwise sincos(a), sqrt(a), a/b computed by the device routines
  * the kernels use (all arrays device, length n). */
 int32_t nbk_selftest_math(const double *a, const double *b, int64_t n, double *sin_out, double *cos_out,

@@ -21,7 +21,7 @@ SYMBOLS = [
     "nbk_fk_batch", "nbk_frameset_create", "nbk_frameset_destroy", "nbk_fk_frames_batch", "nbk_jacobian_batch", "nbk_ik_batch", "nbk_validity_batch", "nbk_validity_workspace_bytes",
     "nbk_validity_batch_ws", "nbk_closest_batch",
     "nbk_pair_distances_batch", "nbk_proximity_jacobian_batch", "nbk_edge_validity_batch", "nbk_selftest_math",
-    "nbk_fk_batch_host", "nbk_validity_batch_host",
+    "nbk_fk_batch_host", "nbk_validity_batch_host", "nbk_knn_prefix",
 ]
 
 
@@ -81,6 +81,7 @@ def load():
     lib.nbk_proximity_jacobian_batch.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     lib.nbk_edge_validity_batch.argtypes = [vp, vp, vp, vp, i64, f64, f64, i32, f64, vp, vp, vp, vp]
     lib.nbk_selftest_math.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
+    lib.nbk_knn_prefix.argtypes = [vp, i32, i32, i32, vp, vp]
     lib.nbk_fk_batch_host.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     lib.nbk_validity_batch_host.argtypes = [vp, vp, i64, f64, vp]
     lib.nbk_model_num_pairs.argtypes = [vp]

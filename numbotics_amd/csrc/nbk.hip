@@ -516,6 +516,73 @@ __global__ __launch_bounds__(64) void k_fk_frames(DevModel m, const double* __re
     }
 }
 
+// ---- exact k nearest neighbours among the points inserted before -----------------------------
+// What an insert-then-query loop over faiss.IndexFlatL2 (numbotics/math/geometry/nearest_neighbors.py:6-85, used by
+// PlanningGraph.k_nearest, planning/sampling_based/graph.py:165-178) returns for point i: the k points of 0..i with the
+// smallest float32 squared L2 distance.  One wave per query; lane l keeps the l-th smallest (distance, index) key seen
+// so far (k <= 64, keys are unique so ties order by index); every chunk of 64 candidates is bitonic-sorted across the
+// lanes and merged -- skipped outright when no candidate beats the current k-th key.
+// distance = sum over the dimensions, in order, of (x - y)^2 with separate float32 roundings (no fma).
+NBK_DEV unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, mask, 64);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+NBK_DEV unsigned long long shfl_u64(unsigned long long v, int src) {
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src, 64);
+    const unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+// ascending bitonic merge of a bitonic sequence spread over the 64 lanes
+NBK_DEV unsigned long long bitonic_merge64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+        const unsigned long long o = shfl_xor_u64(v, j);
+        const bool lower = (lane & j) == 0;
+        v = (lower == (v < o)) ? v : o;
+    }
+    return v;
+}
+NBK_DEV unsigned long long bitonic_sort64(unsigned long long v, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const unsigned long long o = shfl_xor_u64(v, j);
+            const bool up = (lane & k) == 0 || k == 64;          // final pass: whole wave ascending
+            const bool lower = (lane & j) == 0;
+            const bool take_min = lower == up;
+            v = (take_min == (v < o)) ? v : o;
+        }
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_knn_prefix(const float* __restrict__ pts, int N, int dim, int k, int32_t* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
+    const unsigned long long INF_KEY = ~0ull;
+    unsigned long long best = INF_KEY;                            // lane l: l-th smallest key so far
+    const float* x = pts + (size_t)i * dim;
+    for (int j0 = 0; j0 <= i; j0 += WAVE) {
+        const int j = j0 + lane;
+        unsigned long long key = INF_KEY;
+        if (j <= i) {
+            const float* y = pts + (size_t)j * dim;
+            float d = 0.0f;
+            for (int c = 0; c < dim; ++c) { const float t = x[c] - y[c]; const float t2 = t * t; d = d + t2; }
+            key = ((unsigned long long)__builtin_bit_cast(unsigned, d) << 32) | (unsigned)j;
+        }
+        const unsigned long long kth = shfl_u64(best, k - 1);
+        if (__builtin_amdgcn_ballot_w64(key < kth) == 0ull) continue;
+        key = bitonic_sort64(key, lane);
+        // the 64 smallest of best (ascending) and key (ascending): lane-wise min against the reversed other list
+        const unsigned long long rev = shfl_u64(key, 63 - lane);
+        best = bitonic_merge64(best < rev ? best : rev, lane);
+    }
+    if (lane < k) out[(size_t)i * k + lane] = best == INF_KEY ? -1 : (int32_t)(unsigned)(best & 0xFFFFFFFFull);
+}
+
 // ---- batched Levenberg-Marquardt inverse kinematics (Arm.inverse_kinematics, robots/arm.py:464-552) ----------
 // One problem per lane, the whole iteration in one launch:
 //   q <- q + J^T (J J^T + lambda I)^-1 diff,  optional clip to the joint limits,  FK,  diff = [p* - p ; vee(0.5 (R - R^T))]
@@ -2895,6 +2962,14 @@ int32_t nbk_fk_frames_batch(const nbk_model* m, const nbk_frameset* fs, const do
     if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_fk_frames, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, q, B, fs->n, fs->begin, fs->out,
                        fs->local, T_out);
+    NBK_HIP(hipGetLastError());
+    return NBK_OK;
+}
+
+int32_t nbk_knn_prefix(const float* points, int32_t n_points, int32_t dim, int32_t k, int32_t* out_idx, void* stream) {
+    if (n_points < 0 || dim < 1 || dim > 64 || k < 1 || k > 64 || (n_points > 0 && (points == nullptr || out_idx == nullptr))) return NBK_ERR_INVALID;
+    if (n_points == 0) return NBK_OK;
+    hipLaunchKernelGGL(k_knn_prefix, dim3((unsigned)n_points), dim3(WAVE), 0, (hipStream_t)stream, points, n_points, dim, k, out_idx);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }

@@ -285,3 +285,16 @@ def selftest_math(a, b):
     _lib.check(lib.nbk_selftest_math(ta.data_ptr(), tb.data_ptr(), ta.numel(), *[o.data_ptr() for o in outs],
                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nbk_selftest_math")
     return [o.cpu().numpy() for o in outs]
+
+
+def knn_prefix_device(points, k):
+    """(N, d) float32 -> (N, k) int64 neighbour lists among the points inserted before (nbk_knn_prefix), -1 padded."""
+    torch = _require_gpu()
+    lib = _lib.load()
+    x = np.ascontiguousarray(points, dtype=np.float32)
+    n, dim = x.shape
+    t = torch.from_numpy(x).cuda()
+    out = torch.empty((n, k), dtype=torch.int32, device="cuda")
+    _lib.check(lib.nbk_knn_prefix(t.data_ptr(), n, dim, int(k), out.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+               "nbk_knn_prefix")
+    return out.cpu().numpy().astype(np.int64)

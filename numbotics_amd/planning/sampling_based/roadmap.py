@@ -7,7 +7,8 @@ sequential edge walks, each ``ceil(d/res)+1`` PyBullet queries.  The roadmap tho
 on the sample sequence: vertex i is connected to its k nearest among the vertices that existed when it was added
 (itself included, which ``connect`` rejects as a zero-length edge).  ``PRM.plan`` therefore draws the samples
 exactly as ``SamplingPlannerBase.sample_state`` does, finds every neighbour list with an exact float32 L2 scan
-(what ``faiss.IndexFlatL2`` computes; faiss itself is a third-party dependency, tie-breaking parity unpinned),
+(what ``faiss.IndexFlatL2`` computes; faiss itself is a third-party dependency, tie-breaking parity unpinned; on the
+device when there is one: ``nbk_knn_prefix``),
 and hands ALL candidate edges to ``DiscreteConnector.connect_batch`` -- one launch sequence on the device.
 
 Only what PRM needs is here: the state space, the planner parameters, the roadmap (arrays + a SciPy Dijkstra
@@ -94,17 +95,33 @@ class Node:
     cost: float = np.inf
 
 
-def knn_prefix(points: np.ndarray, k: int, chunk: int = 2048):
-    """For every i: the indices of the (at most k) nearest points among points[0..i] (float32 squared L2, ascending,
-    ties to the smaller index) -- the neighbour lists an insert-then-query loop over an exact flat index yields.
-    -> (N, k) int64, -1 padded."""
+def knn_prefix(points: np.ndarray, k: int, chunk: int = 1024, device=None):
+    """For every i: the indices of the (at most k) nearest points among points[0..i] -- the neighbour lists an
+    insert-then-query loop over an exact flat L2 index yields.  -> (N, k) int64, -1 padded.
+
+    Distance = sum over the dimensions, in order, of (x - y)^2 in float32 (separate roundings); order = ascending
+    (distance, index).  ``device``: None = the GPU kernel (``nbk_knn_prefix``) when a GPU is visible and k <= 64, else
+    NumPy; True / False force one.  Both give identical lists."""
     x = np.ascontiguousarray(points, dtype=np.float32)
-    n = x.shape[0]
+    n, dim = x.shape
+    if device is None:
+        device = False
+        if k <= 64 and dim <= 64 and n > 0:
+            try:
+                import torch
+                device = torch.cuda.is_available()
+            except Exception:
+                device = False
+    if device:
+        from numbotics_amd.engine import knn_prefix_device
+        return knn_prefix_device(x, k)
     out = np.full((n, k), -1, dtype=np.int64)
-    sq = (x * x).sum(axis=1)
     for a in range(0, n, chunk):
         b = min(n, a + chunk)
-        d = sq[a:b, None] - 2.0 * (x[a:b] @ x[:b].T) + sq[None, :b]
+        d = np.zeros((b - a, b), dtype=np.float32)
+        for c in range(dim):
+            t = x[a:b, None, c] - x[None, :b, c]
+            d += t * t
         d[np.arange(b - a)[:, None] + a < np.arange(b)[None, :]] = np.inf        # only points that already exist
         kk = min(k, b)
         # the kk smallest of every row without sorting the row: partition, then resolve ties at the k-th value

@@ -764,6 +764,20 @@ def test_fk_of_all_links_in_one_sweep(fresh_world, robot, torch_cuda):
         arm.forward_kinematics_all(q, frames=["nope"])
 
 
+def test_device_knn_matches_the_host_scan(torch_cuda):
+    """nbk_knn_prefix == the NumPy restatement of the insert-then-query flat L2 index, index for
+    index (ties, duplicates, fewer than k points, k up to 64)."""
+    from numbotics_amd.planning.sampling_based import knn_prefix
+    rng = np.random.default_rng(3)
+    for n, dim, k in ((3000, 7, 50), (2000, 2, 8), (1500, 13, 64), (700, 7, 1), (40, 5, 64)):
+        x = rng.normal(size=(n, dim))
+        assert np.array_equal(knn_prefix(x, k, device=True), knn_prefix(x, k, device=False)), (n, dim, k)
+    grid = rng.integers(0, 4, size=(1200, 3)).astype(np.float64)           # many exact ties and duplicate points
+    assert np.array_equal(knn_prefix(grid, 20, device=True), knn_prefix(grid, 20, device=False))
+    from numbotics_amd import _lib
+    assert _lib.load().nbk_knn_prefix(None, 10, 3, 65, None, None) == -1
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""

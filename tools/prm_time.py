@@ -24,6 +24,6 @@ for n in (2000, 10000):
     t3 = time.perf_counter()
     for a, b in ce[live][:m]: conn.connect(nodes[a], nodes[b], distance_func=space.distance)
     t4 = time.perf_counter()
-    print('PRM %d samples, k=50: %d candidate edges; host kNN + edge list %.3f s; connect_batch %.4f s (%.3e edges/s, PCIe incl.); '
+    print('PRM %d samples, k=50: %d candidate edges; kNN (nbk_knn_prefix) + edge list %.3f s; connect_batch %.4f s (%.3e edges/s, PCIe incl.); '
           'scalar connect() %.3e edges/s -> %.1f s for the same roadmap; accepted %.3f' % (
           n, live.sum(), t1 - t0, t2 - t1, live.sum() / (t2 - t1), m / (t4 - t3), live.sum() * (t4 - t3) / m, ok.mean()))
