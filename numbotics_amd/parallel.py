@@ -73,3 +73,59 @@ def sharded_validity(validity_words_fn, q_full, total: int):
         pad = torch.zeros((n_words - words.numel(),), dtype=words.dtype, device=words.device)
         words = torch.cat([words, pad])
     return allgather_mask_words(words)
+
+
+def pack_bits(flags) -> np.ndarray:
+    """(n,) bool -> ceil(n/64) int64 words, bit i%64 of word i//64 (the layout of the device's packed masks)."""
+    m = np.ascontiguousarray(flags, dtype=bool)
+    pad = (-len(m)) % 64
+    bits = np.concatenate([m, np.zeros(pad, dtype=bool)]).reshape(-1, 64)
+    return (bits.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1, dtype=np.uint64).view(np.int64)
+
+
+def sharded_edge_validity(edge_valid_fn, starts, goals, total: int):
+    """Edge batches shard exactly like configurations: rank r checks edges [lo, hi) and the E validity bits are
+    gathered with the same collective.  `edge_valid_fn(starts, goals) -> (n,) bool` is
+    `DiscreteConnector.connect_batch` in production.  Returns the packed words of all E edges on every rank."""
+    def words_fn(idx):
+        lo, hi = idx
+        ok = edge_valid_fn(starts[lo:hi], goals[lo:hi]) if hi > lo else np.zeros((0,), dtype=bool)
+        import torch
+        if torch.is_tensor(ok):
+            ok = ok.cpu().numpy()
+        return pack_bits(np.asarray(ok))
+
+    class _Ranges:                                     # lets sharded_validity slice "the batch" into (lo, hi) itself
+        def __getitem__(self, s):
+            return (s.start, s.stop)
+    return sharded_validity(words_fn, _Ranges(), total)
+
+
+def sharded_records(record_fn, q_full, total: int, width: int):
+    """Per-sample float64 records (config 5: distance, pair id, contact points, gradient row ... `width` values per
+    sample): rank r computes rows [lo, hi), one all_gather_into_tensor of equal (padded) shards returns all rows."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_bounds(total, world, rank)
+    per = shard_words(total, world) * 64
+    rec = record_fn(q_full[lo:hi]) if hi > lo else np.zeros((0, width))
+    if not torch.is_tensor(rec):
+        rec = torch.from_numpy(np.ascontiguousarray(rec, dtype=np.float64))
+    rec = rec.reshape(-1, width)
+    if rec.shape[0] < per:
+        rec = torch.cat([rec, torch.zeros((per - rec.shape[0], width), dtype=rec.dtype, device=rec.device)])
+    if world == 1:
+        return rec[:total]
+    out = torch.empty((world * per, width), dtype=rec.dtype, device=rec.device)
+    if dist.get_backend() == "gloo" and rec.is_cuda:
+        host = torch.empty((world * per, width), dtype=rec.dtype)
+        dist.all_gather_into_tensor(host, rec.cpu().contiguous())
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, rec.contiguous())
+    # shards are contiguous blocks of `per` rows; drop each shard's padding
+    keep = torch.cat([torch.arange(r * per, r * per + (shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0]))
+                      for r in range(world)])
+    return out[keep.to(out.device)]

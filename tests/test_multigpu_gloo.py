@@ -71,6 +71,54 @@ def test_sharded_mask_allgather_gloo(total, fresh_world):
     assert ret[0][1] == 0 and ret[world - 1][2] == total
 
 
+def _worker_edges_records(rank, world, port, E, starts, goals, M, pts, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from numbotics_amd.physics import World
+        from numbotics_amd.scenes import build_scene
+        from numbotics_amd.parallel import sharded_edge_validity, sharded_records, unpack_mask
+        from oracle.cpu_oracle import Oracle
+        World()
+        arm, chain, obs = build_scene("c2")
+        orc = Oracle(arm.scene_model())
+        words = sharded_edge_validity(lambda s, g: orc.edge_validity(s, g, 0.05, np.pi, mode="connect")[0], starts, goals, E)
+
+        def records(qs):
+            d, idx = orc.closest(qs)
+            return np.stack([d, idx.astype(np.float64)], axis=1)
+        rec = sharded_records(records, pts, M, 2)
+        ret[rank] = (words.numpy().copy(), rec.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_edges_and_records_gloo(fresh_world):
+    """Edge bits and per-sample records (config 3 / config 5 of SURVEY.md 8e) through the same shard + all-gather path."""
+    from numbotics_amd.scenes import build_scene, sample_q
+    from numbotics_amd.parallel import shard_bounds, shard_words, unpack_mask
+    from oracle.cpu_oracle import Oracle
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    E, M, world = 150, 201, 2
+    q = sample_q(chain, 2 * E + M, seed=6)
+    starts, goals, pts = q[:E], q[E:2 * E], q[2 * E:]
+    ok = orc.edge_validity(starts, goals, 0.05, np.pi, mode="connect")[0]
+    d, idx = orc.closest(pts)
+    port = 31500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_edges_records, args=(world, port, E, starts, goals, M, pts, ret), nprocs=world, join=True)
+    per = shard_words(E, world) * 64
+    for r in range(world):
+        words, rec = ret[r]
+        bits = unpack_mask(words, world * per)
+        got = np.concatenate([bits[k * per:k * per + (shard_bounds(E, world, k)[1] - shard_bounds(E, world, k)[0])] for k in range(world)])
+        assert np.array_equal(got, ok)
+        assert rec.shape == (M, 2) and np.array_equal(rec[:, 0], d) and np.array_equal(rec[:, 1].astype(np.int32), idx)
+
+
 def test_shard_bounds_cover_and_align():
     from numbotics_amd.parallel import shard_bounds
     for total in (0, 1, 63, 64, 65, 1000, 10_000_000):
