@@ -187,6 +187,7 @@ class PRM:
         verts = [np.asarray(self._start, dtype=np.float64)]
         targets = []                                   # per iteration: node index of new_node
         goal_hits = []                                 # (iteration position, goal index, vertex count at that time)
+        self._node_counts = []                         # graph nodes (vertices + goals) when each iteration queried its neighbours
         for s in samples:
             for gi, g in enumerate(self._goals):
                 if self._space.distance(s, g) < p.goal_tolerance:
@@ -196,16 +197,18 @@ class PRM:
             else:
                 verts.append(np.asarray(s, dtype=np.float64))
                 targets.append(len(verts) - 1)
+            self._node_counts.append(len(verts) + len(self._goals))
         V = np.vstack(verts).reshape(-1, d)
         nv = V.shape[0]
         nbr = knn_prefix(V, p.k_nearest)
-        src, dst = [], []
-        for t in targets:
+        src, dst, cnt = [], [], []
+        for it, t in enumerate(targets):
             if t >= 0:
                 row = nbr[t]
                 row = row[row >= 0]
                 src.append(row)
                 dst.append(np.full(row.shape, t, dtype=np.int64))
+                cnt.append(np.full(row.shape, self._node_counts[it], dtype=np.int64))
         # a sample that landed on a goal: k nearest vertices of the goal state among those present at that time
         x32 = V.astype(np.float32)
         for gi, count in goal_hits:
@@ -214,11 +217,19 @@ class PRM:
             row = np.argsort(dd, kind="stable")[:p.k_nearest]
             src.append(row.astype(np.int64))
             dst.append(np.full(row.shape, nv + gi, dtype=np.int64))
+            cnt.append(np.full(row.shape, count + len(self._goals), dtype=np.int64))
         src = np.concatenate(src) if src else np.zeros((0,), dtype=np.int64)
         dst = np.concatenate(dst) if dst else np.zeros((0,), dtype=np.int64)
+        cnt = np.concatenate(cnt) if cnt else np.zeros((0,), dtype=np.int64)
         nodes = np.vstack([V] + [np.asarray(g, dtype=np.float64)[None] for g in self._goals])
+        keep = self._neighbour_filter(nodes[src], nodes[dst], cnt)
+        src, dst = src[keep], dst[keep]
         dist = np.asarray(self._space.distance_batch(nodes[src], nodes[dst]), dtype=np.float64).reshape(-1)
         return V, nodes, np.stack([src, dst], axis=1), dist
+
+    def _neighbour_filter(self, near, state, node_count):
+        """Which of the k nearest are kept (graph.py:170: ``norm(q_near - state) < radius``); PRM: radius = inf."""
+        return np.ones((near.shape[0],), dtype=bool)
 
     def plan(self, samples=None):
         if self._start is None:
@@ -262,3 +273,64 @@ class PRM:
         path.reverse()
         name = lambda i: f"v_{i}" if i < nv else f"g_{i - nv}"      # noqa: E731
         return [Node(id=name(i), state=self._nodes[i], cost=float(dist[i])) for i in path]
+
+
+class PRMStar(PRM):
+    """prm_star.py:14-58: PRM whose neighbours must also lie within the shrinking connection radius
+    ``gamma (log n / n)^(1/d)``, n = graph nodes when the sample is inserted."""
+
+    def connection_radius(self, n_nodes):
+        from scipy.special import gamma as _gamma
+        dim = float(self._space.dimension)
+        k = np.asarray(n_nodes, dtype=np.float64)
+        V_ball = (np.pi ** (dim / 2.0)) / _gamma((dim / 2.0) + 1.0)
+        V_space = self._space.volume
+        g = 2.0 * (1.0 + (1.0 / dim)) ** (1.0 / dim) * (V_ball / V_space) ** (1.0 / dim)
+        return g * (np.log(k) / k) ** (1 / dim)
+
+    def _neighbour_filter(self, near, state, node_count):
+        return np.linalg.norm(near - state, axis=1) < self.connection_radius(node_count)
+
+
+class RRT(PRM):
+    """rrt.py:13-52: the tree grows one steer at a time (each ``steer`` is one device launch over the whole edge);
+    nothing to batch across iterations, provided for completeness of the planner family."""
+
+    def plan(self, samples=None):
+        if self._start is None:
+            raise ValueError("Must set start state before planning")
+        if len(self._goals) == 0:
+            raise ValueError("Must set goal states before planning")
+        p = self._params
+        verts = [np.asarray(self._start, dtype=np.float64)]
+        edges, weights = [], []
+        n_goal_edges = 0
+        it = iter(samples) if samples is not None else None
+        for _ in range(p.max_iters):
+            rand_state = next(it) if it is not None else self.sample_state()
+            X = np.asarray(verts, dtype=np.float32)
+            d = ((X - np.asarray(rand_state, dtype=np.float32)) ** 2).sum(axis=1)
+            near = int(np.argmin(d))
+            new_state = self._connector.steer(verts[near], rand_state, distance_func=self._space.distance)
+            if new_state is None:
+                continue
+            for gi, g in enumerate(self._goals):
+                if self._space.distance(new_state, g) < p.goal_tolerance:
+                    edges.append((near, -1 - gi))
+                    weights.append(self._space.distance(new_state, g))
+                    n_goal_edges += 1
+                    break
+            else:
+                verts.append(np.asarray(new_state, dtype=np.float64))
+                edges.append((near, len(verts) - 1))
+                weights.append(self._space.distance(verts[near], new_state))
+                continue
+            break
+        V = np.vstack(verts)
+        nv = V.shape[0]
+        self.states = V
+        self._nodes = np.vstack([V] + [np.asarray(g, dtype=np.float64)[None] for g in self._goals])
+        e = np.array([(a, b if b >= 0 else nv + (-1 - b)) for a, b in edges], dtype=np.int64).reshape(-1, 2)
+        self.edges, self.weights = e, np.asarray(weights, dtype=np.float64)
+        self.n_candidate_edges = len(edges)
+        return self

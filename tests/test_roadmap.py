@@ -94,3 +94,92 @@ def test_knn_prefix_is_an_insert_then_query_index():
         want = np.argsort(d, kind="stable")[:6]
         got = nb[i][nb[i] >= 0]
         assert set(got.tolist()) == set(want.tolist()) and got[0] == i
+
+
+def test_prm_star_radius_filter_matches_the_sequential_loop():
+    """prm_star.py:21-58: neighbours beyond gamma (log n / n)^(1/d) are dropped, n = graph nodes at insertion time."""
+    from numbotics_amd.planning.sampling_based import PRMStar
+    from scipy.special import gamma as G
+    rng = np.random.default_rng(5)
+    space = EuclideanSpace(np.zeros(2), 2.0 * np.ones(2))
+    params = PlannerParams(max_iters=250, k_nearest=60, goal_bias=0.04)
+    start, goal = np.array([0.1, 0.1]), np.array([1.9, 1.9])
+    samples = [goal.copy() if rng.random() < params.goal_bias else rng.uniform(0, 2, 2) for _ in range(params.max_iters)]
+    conn = DiskWorldConnector([1.0, 1.0], 0.4)
+    # the reference loop, one iteration at a time
+    verts, ref_edges = [start], []
+    for s in samples:
+        if space.distance(s, goal) < params.goal_tolerance:
+            node = ("g", 0, goal)
+        else:
+            verts.append(s)
+            node = ("v", len(verts) - 1, s)
+        n_nodes = float(len(verts) + 1)
+        V_ball = (np.pi ** 1.0) / G(2.0)
+        radius = 2.0 * (1.5 ** 0.5) * (V_ball / 4.0) ** 0.5 * (np.log(n_nodes) / n_nodes) ** 0.5
+        X = np.asarray(verts, dtype=np.float32)
+        d = ((X - np.asarray(node[2], dtype=np.float32)) ** 2).sum(axis=1)
+        near = np.argsort(d, kind="stable")[:params.k_nearest]
+        near = near[np.linalg.norm(np.asarray(verts)[near] - node[2], axis=1) < radius]
+        for j in near:
+            if conn.connect(verts[j], node[2], distance_func=space.distance) is not None:
+                ref_edges.append((int(j), node[0], node[1]))
+    prm = PRMStar(space, DiskWorldConnector([1.0, 1.0], 0.4), params)
+    prm.add_start(start)
+    prm.add_goal(goal)
+    prm.plan(samples)
+    nv = prm.states.shape[0]
+    got = sorted((int(a), "v" if b < nv else "g", int(b if b < nv else b - nv)) for a, b in prm.edges)
+    assert got == sorted(ref_edges) and len(got) > 50
+    plain = PRM(space, DiskWorldConnector([1.0, 1.0], 0.4), params)
+    plain.add_start(start)
+    plain.add_goal(goal)
+    plain.plan(samples)
+    assert prm.n_candidate_edges < 0.9 * plain.n_candidate_edges     # the radius does cut candidates
+
+
+class SteeringDiskWorld(DiskWorldConnector):
+    def steer(self, a, b, distance_func=lambda x, y: np.linalg.norm(x - y), max_distance=0.15):
+        d = distance_func(a, b)
+        if d <= np.finfo(np.float32).eps:
+            return None
+        Tf = 1.0 if d <= max_distance else max_distance / d
+        T = np.append(np.arange(0.0, Tf, self.res / d), Tf)
+        for t in T:
+            if not self.is_valid((1 - t) * a + t * b):
+                return None
+        return (1 - Tf) * a + Tf * b
+
+
+def test_rrt_grows_the_reference_tree():
+    """rrt.py:19-52 restated: nearest vertex, steer, add; stops at the first vertex within goal_tolerance of a goal."""
+    from numbotics_amd.planning.sampling_based import RRT
+    rng = np.random.default_rng(6)
+    space = EuclideanSpace(np.zeros(2), np.ones(2))
+    params = PlannerParams(max_iters=1500, goal_bias=0.1, goal_tolerance=0.05)
+    start, goal = np.array([0.05, 0.05]), np.array([0.95, 0.95])
+    samples = [goal.copy() if rng.random() < params.goal_bias else rng.uniform(0, 1, 2) for _ in range(params.max_iters)]
+    conn = SteeringDiskWorld([0.5, 0.5], 0.25)
+    verts, ref_edges, reached = [start], [], False
+    for s in samples:
+        X = np.asarray(verts, dtype=np.float32)
+        near = int(np.argmin(((X - np.asarray(s, dtype=np.float32)) ** 2).sum(axis=1)))
+        new = conn.steer(verts[near], s, distance_func=space.distance)
+        if new is None:
+            continue
+        if space.distance(new, goal) < params.goal_tolerance:
+            ref_edges.append((near, "g"))
+            reached = True
+            break
+        verts.append(new)
+        ref_edges.append((near, len(verts) - 1))
+    rrt = RRT(space, SteeringDiskWorld([0.5, 0.5], 0.25), params)
+    rrt.add_start(start)
+    rrt.add_goal(goal)
+    rrt.plan(samples)
+    nv = rrt.states.shape[0]
+    assert reached and nv == len(verts) and np.array_equal(rrt.states, np.asarray(verts))
+    got = [(int(a), "g" if b >= nv else int(b)) for a, b in rrt.edges]
+    assert got == ref_edges
+    path = rrt.solution()
+    assert path is not None and path[0].id == "v_0" and path[-1].id == "g_0" and len(path) > 5
