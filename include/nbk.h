@@ -140,6 +140,7 @@ int32_t nbk_ik_batch(const nbk_model *m, const double *pose, const double *q0, i
  * iff min over the allowed pairs of the signed distance is < threshold (strict).  Replaces the
  * per-configuration PyBullet round trip Arm.collisions -> Chain.distance_to -> getClosestPoints
  * (arm.py:555-580, numbotics/physics/chain.py:944-969).
+ * A configuration with a NaN or infinite joint value is reported as colliding.
  *   mask_bits  (device, optional) [ceil(B/64)] uint64, bit (b % 64) of word (b / 64);
  *   mask_bytes (device, optional) [B] uint8.  At least one must be given.
  */

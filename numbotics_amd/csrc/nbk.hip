@@ -147,6 +147,14 @@ NBK_DEV void stage_q(const double* __restrict__ q, int64_t base, int64_t B, int 
     __syncthreads();
 }
 
+// A configuration with a NaN or infinite joint value is reported as colliding by every validity path (the planner must
+// not accept it); `row` points at the lane's first value, `stride` is the distance between consecutive joints.
+NBK_DEV bool row_nonfinite(const double* row, int n, int stride) {
+    bool bad = false;
+    for (int j = 0; j < n; ++j) bad = bad || !(__builtin_fabs(row[j * stride]) <= 1.7976931348623157e308);
+    return bad;
+}
+
 // child frame of joint k (robots/helpers.py:43-55 restated with the host-made M0/M1/M2)
 NBK_DEV void joint_apply(const DevModel& m, int k, const Xf& parent, double qk, Xf& out) {
     const double* M = m.joint_rot + 27 * k;
@@ -984,7 +992,8 @@ __global__ __launch_bounds__(64) void k_validity(DevModel m, const double* __res
     stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
     const bool active = (base + lane) < B;
     sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
-    const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active);
+    const bool bad = row_nonfinite(lds_q + lane, m.n_q, WAVE);
+    const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active) || bad;
     const uint64_t word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
@@ -1186,7 +1195,7 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
     for (int i = lane; i < 18 * m.n_wshapes; i += WAVE) lds_w[i] = m.ws_core[i];
     __syncthreads();
     const bool active = lane < rows_i;
-    bool hit = false;
+    bool hit = row_nonfinite(lds_raw + lane * nq, nq, 1);        // non-finite joint values: colliding, nothing queued
     // ---- sweep: centres only ----------------------------------------------------------------------------------
     {
         Xf bpose;
@@ -1380,7 +1389,7 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
     }
     __syncthreads();
     const bool active = lane < rows_i;
-    bool hit = false;
+    bool hit = row_nonfinite(lds_raw + lane * nq, nq, 1);        // non-finite joint values: colliding, nothing queued
     // ---- sweep: centres into registers ---------------------------------------------------------------------------------------
     double cx[S], cy[S], cz[S];
     {
@@ -1620,7 +1629,7 @@ __global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, con
     }
     __syncthreads();
     const bool active = lane < rows_i;
-    bool hit = false;
+    bool hit = row_nonfinite(lds_raw + lane * nq, nq, 1);        // non-finite joint values: colliding, nothing queued
     // ---- sweep in float32: centres into registers ---------------------------------------------------------------------------
     float cx[S], cy[S], cz[S];
     float rmax = m.f_reach, qabs = 0.0f;
@@ -2378,7 +2387,7 @@ __global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restri
         for (int i = 0; i < nq; ++i) { const double df = g[i] - s[i]; acc = NBK_FMA(df, df, acc); }
         d = nbk_sqrt(acc);
     }
-    if (!(d > 1.1920928955078125e-07)) {   // float32 eps: the reference returns None
+    if (!(d > 1.1920928955078125e-07 && d <= 1.7976931348623157e308)) {   // float32 eps: the reference returns None
         if (lane == 0) { valid[e] = 0; if (n_samples) n_samples[e] = 0; }
         if (end != nullptr && lane < nq) end[e * nq + lane] = __builtin_nan("");
         return;
@@ -2398,8 +2407,9 @@ __global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restri
             const double bb = t * g[j];
             lds_q[j * WAVE + lane] = a + bb;
         }
+        const bool bad = row_nonfinite(lds_q + lane, nq, WAVE);
         sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
-        const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active);
+        const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active) || bad;
         if (__builtin_amdgcn_ballot_w64(hit && active) != 0ull) ok = false;
     }
     if (lane == 0) { valid[e] = ok ? 1 : 0; if (n_samples) n_samples[e] = (int32_t)(n + 1); }
@@ -2444,7 +2454,7 @@ __global__ void k_edge_plan(int nq, const double* __restrict__ starts, const dou
         for (int i = 0; i < nq; ++i) { const double df = g[i] - s[i]; acc = NBK_FMA(df, df, acc); }
         d = nbk_sqrt(acc);
     }
-    if (!(d > 1.1920928955078125e-07)) {
+    if (!(d > 1.1920928955078125e-07 && d <= 1.7976931348623157e308)) {
         plan[3 * e] = 0.0; plan[3 * e + 1] = 0.0; plan[3 * e + 2] = 0.0;
         cnt[e] = 0ull;
         if (n_samples) n_samples[e] = 0;
@@ -3074,7 +3084,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         uint8_t* my = mask_bytes ? mask_bytes + b0 : nullptr;
         const int S = m->d.n_rshapes;
         const bool use_reg = S <= 16 && !getenv("NBK_NO_REG_BROAD");
-        static const bool f32 = !getenv("NBK_F64_BROAD");
+        const bool f32 = !getenv("NBK_F64_BROAD");
         float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
         const size_t qrows_f = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);

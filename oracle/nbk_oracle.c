@@ -1203,12 +1203,19 @@ typedef struct {
     const orc_model *m; const double *q; int64_t b0, b1; double thr; uint8_t *mask; const core_t *wc;
 } vjob_t;
 
+/* a configuration with a NaN or infinite joint value counts as colliding (a planner must not accept it) */
+static int q_nonfinite(const double *q, int n) {
+    for (int j = 0; j < n; ++j) if (!(fabs(q[j]) <= DBL_MAX)) return 1;
+    return 0;
+}
+
 static void *validity_worker(void *arg) {
     vjob_t *j = (vjob_t *)arg;
     const orc_model *m = j->m;
     xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
     core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
     for (int64_t b = j->b0; b < j->b1; ++b) {
+        if (q_nonfinite(j->q + b * m->n_q, m->n_q)) { j->mask[b] = 1; continue; }
         robot_cores(m, j->q + b * m->n_q, frames, rc);
         uint8_t hit = 0;
         for (int p = 0; p < m->n_pairs && !hit; ++p)
@@ -1255,7 +1262,7 @@ static void edge_point(int32_t n_q, const double *s, const double *g, double t, 
 }
 /* returns n = len(arange) (so n+1 samples) or -1 for the degenerate edge; writes T_f and step */
 static int64_t edge_plan(double d, double resolution, double max_distance, int mode, double *Tf, double *step) {
-    if (!(d > (double)FLT_EPSILON)) return -1;
+    if (!(d > (double)FLT_EPSILON && d <= DBL_MAX)) return -1;      /* too short (the reference returns None) or not finite */
     *Tf = (mode == 1 && d > max_distance) ? max_distance / d : 1.0;
     *step = resolution / d;
     const double len = ceil(*Tf / *step);
@@ -1300,6 +1307,7 @@ static void *edge_worker(void *arg) {
         uint8_t ok = 1;
         for (int64_t i = 0; i <= n && ok; ++i) {
             edge_point(nq, s, g, i < n ? (double)i * step : Tf, qs);
+            if (q_nonfinite(qs, nq)) { ok = 0; break; }
             robot_cores(m, qs, frames, rc);
             for (int p = 0; p < m->n_pairs; ++p)
                 if (pair_hit(m, rc, j->wc, p, j->thr)) { ok = 0; break; }

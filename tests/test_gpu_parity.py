@@ -778,6 +778,34 @@ def test_device_knn_matches_the_host_scan(torch_cuda):
     assert _lib.load().nbk_knn_prefix(None, 10, 3, 65, None, None) == -1
 
 
+def test_non_finite_joint_values_count_as_colliding(fresh_world, torch_cuda):
+    """NaN / inf joint values: every validity path (fused, two-kernel float32 and float64 broadphase, edges) reports the
+    configuration as colliding, like the oracle."""
+    import os
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    q = sample_q(chain, 9000, seed=91)
+    rng = np.random.default_rng(1)
+    bad_rows = rng.choice(9000, 300, replace=False)
+    q[bad_rows, rng.integers(0, 7, 300)] = rng.choice([np.nan, np.inf, -np.inf], 300)
+    ref = orc.validity(q, 0.0, nthreads=8)
+    assert ref[bad_rows].all()
+    assert np.array_equal(arm.in_collision(q, 0.0), ref)                       # float32 broadphase
+    assert np.array_equal(arm.in_collision(q[:3000], 0.0), ref[:3000])         # fused kernel
+    for flag in ("NBK_F64_BROAD", "NBK_NO_REG_BROAD"):                         # float64 register / LDS broadphase
+        os.environ[flag] = "1"
+        try:
+            assert np.array_equal(arm.in_collision(q, 0.0), ref), flag
+        finally:
+            del os.environ[flag]
+    _, dev = arm._scene_device()
+    s_, g_ = q[:200].copy(), q[200:400].copy()
+    ok, end, ns = dev.edge_validity(s_, g_, 0.05, 1.5, mode="connect")
+    okr, endr, nsr = orc.edge_validity(s_, g_, 0.05, 1.5, mode="connect")
+    finite = np.isfinite(s_).all(axis=1) & np.isfinite(g_).all(axis=1)
+    assert np.array_equal(ok[finite], okr[finite]) and not ok[~finite].any() and not okr[~finite].any()
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
