@@ -1582,7 +1582,7 @@ NBK_DEV void joint_apply_f(const DevModel& m, int k, const XfF& P, float qk, XfF
 }
 
 template <int S>
-__global__ __launch_bounds__(64, 5) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
+__global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                    uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                                                    unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
                                                    unsigned long long cap, const float* __restrict__ tab) {
