@@ -2110,9 +2110,11 @@ __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(Dev
                                                       const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
     __shared__ double pool[POOL_E * POOL_CAP_BOOL];
-    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
     __shared__ int pool_n, pool_next;
-    narrow_body<true, POOL_CAP_BOOL>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, qstage, pool_n, pool_next);
+    // the staged q rows (NARROW_T * n_q doubles) live in the pool's memory: the wave has left the FK replay, the last reader
+    // of q, before its first pool_put (one wave per workgroup) -- 18.4 KB of LDS per workgroup, 8 workgroups per CU
+    static_assert(POOL_E * POOL_CAP_BOOL >= NARROW_T * NBK_MAX_DOF, "q rows must fit the pool");
+    narrow_body<true, POOL_CAP_BOOL>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, pool, pool_n, pool_next);
 }
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
@@ -2120,9 +2122,9 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
     __shared__ double pool[POOL_E * NARROW_T];
-    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
     __shared__ int pool_n, pool_next;
-    narrow_body<false, NARROW_T>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, qstage, pool_n, pool_next);
+    static_assert(POOL_E * NARROW_T >= NARROW_T * NBK_MAX_DOF, "q rows must fit the pool");
+    narrow_body<false, NARROW_T>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, pool, pool_n, pool_next);
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses;
@@ -3108,7 +3110,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         else
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q;
+        const size_t nlds = 0;
         if (threshold == 0.0 && m->margins_zero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * 32), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         else
