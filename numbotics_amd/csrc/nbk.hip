@@ -1818,69 +1818,16 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
     }
 }
 
-// k_narrow: 128-thread workgroups take 128 queue items at a time.
-//   phase 1 (one item per lane, dense): FK replay of the item's two primitives, cores, planes / box midphase /
-//            closed forms; what is left for GJK is serialised into an LDS pool (36 doubles per item,
-//            component-major so that consecutive slots do not collide on banks);
-//   phase 2 (dynamic): every lane runs the GJK predicate ONE iteration per trip and, when its item is decided,
-//            takes the next pooled item -- iteration counts differ a lot between items (mean 2.2, max ~8), so a
-//            static item-to-lane assignment leaves two thirds of the lanes idle.
+// k_narrow: one 64-lane workgroup takes 64 queue items at a time.
+//   phase 1 (one item per lane, dense): FK replay of the item's two primitives, cores, the float64 bounding-sphere
+//            step, planes / box midphase / closed forms;
+//   phase 2: the lanes whose item is still undecided walk GJK, one iteration per trip of the wave, until the last one
+//            has its verdict (iteration counts differ: mean 4, max ~10 per chunk).  An LDS pool that handed finished
+//            lanes new items existed while chunks were larger than the wave; with 64-item chunks it never had
+//            anything left to hand out and only cost 18 KB of LDS per workgroup.
 constexpr int NARROW_T = 64;
-constexpr int POOL_E = 36;
-constexpr int NARROW_WAVES_BOOL = 2;     // waves per SIMD the boolean-only narrowphase is compiled for (3 fits only with ~120 spilled
-                                         // registers and a 32-slot pool: measured no faster)
-constexpr int POOL_CAP_BOOL = NARROW_T;  // pool slots of the boolean-only kernel (fewer slots = less LDS; overflow is then decided in place)
-
-template <int STRIDE>
-NBK_DEV void pool_put(double* pool, int slot, const Core& A, const Core& Bc, double tc, long long b) {
-    double* p = pool + slot;
-    const Core* cs[2] = {&A, &Bc};
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const Core& o = *cs[c];
-        const int e0 = 17 * c;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            p[(e0 + e) * STRIDE] = o.c[e];
-            p[(e0 + 3 + e) * STRIDE] = o.ax[0][e];
-            p[(e0 + 6 + e) * STRIDE] = o.ax[1][e];
-            p[(e0 + 9 + e) * STRIDE] = o.ax[2][e];
-            p[(e0 + 12 + e) * STRIDE] = o.h[e];
-        }
-        p[(e0 + 15) * STRIDE] = o.rad;
-        p[(e0 + 16) * STRIDE] = o.margin;
-    }
-    p[34 * STRIDE] = tc;
-    const unsigned long long packed = ((unsigned long long)b << 8) | ((unsigned long long)(unsigned)A.kind << 4) | (unsigned long long)(unsigned)Bc.kind;
-    p[35 * STRIDE] = __builtin_bit_cast(double, packed);
-}
-
-template <int STRIDE>
-NBK_DEV void pool_get(const double* pool, int slot, Core& A, Core& Bc, double& tc, long long& b) {
-    const double* p = pool + slot;
-    const unsigned long long packed = __builtin_bit_cast(unsigned long long, p[35 * STRIDE]);
-    b = (long long)(packed >> 8);
-    A.kind = (int)((packed >> 4) & 15ull);
-    Bc.kind = (int)(packed & 15ull);
-    Core* cs[2] = {&A, &Bc};
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        Core& o = *cs[c];
-        const int e0 = 17 * c;
-#pragma unroll
-        for (int e = 0; e < 3; ++e) {
-            o.c[e] = p[(e0 + e) * STRIDE];
-            o.ax[0][e] = p[(e0 + 3 + e) * STRIDE];
-            o.ax[1][e] = p[(e0 + 6 + e) * STRIDE];
-            o.ax[2][e] = p[(e0 + 9 + e) * STRIDE];
-            o.h[e] = p[(e0 + 12 + e) * STRIDE];
-        }
-        o.rad = p[(e0 + 15) * STRIDE];
-        o.margin = p[(e0 + 16) * STRIDE];
-        o.rho = 0.0;
-    }
-    tc = p[34 * STRIDE];
-}
+constexpr int NARROW_WAVES_BOOL = 2;     // waves per SIMD the boolean-only narrowphase is compiled for (3 needs ~120 spilled
+                                         // registers: measured slower)
 
 NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
     if (mask_bits != nullptr) atomicOr(reinterpret_cast<unsigned long long*>(mask_bits) + (b >> 6), 1ull << (b & 63));
@@ -1894,11 +1841,11 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
 __device__ unsigned long long g_narrow_prof[16];
 #define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
 
-template <bool BOOL_ONLY, int POOL_CAP>
+template <bool BOOL_ONLY>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
                          const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
                          unsigned long long cap, uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
-                         double* pool, double* qstage, int& pool_n, int& pool_next) {
+                         double* qstage) {
     // block (sub, part): every nparts-th 128-item chunk of sub-queue `sub`
     const unsigned sub = blockIdx.x % NSUB;
     const unsigned part = blockIdx.x / NSUB;
@@ -1917,10 +1864,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     unsigned long long n = __hip_atomic_load(q_count + sub * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > cap) n = cap;
     if (m.dbg & 1) n = 0;
-    const int lane = threadIdx.x & 63;
     for (unsigned long long i0 = (unsigned long long)part * NARROW_T; i0 < n; i0 += (unsigned long long)nparts * NARROW_T) {
-        if (threadIdx.x == 0) { pool_n = 0; pool_next = 0; }
-        __syncthreads();
         // ---- phase 1 -----------------------------------------------------------------------------------------------
         {
             const unsigned long long i = i0 + threadIdx.x;
@@ -1984,6 +1928,10 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             bool pooled = false;
             Core A, Bc;
             double tc = 0.0;
+            A.kind = K_POINT; Bc.kind = K_POINT;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) { A.c[e] = 0.0; Bc.c[e] = 1.0; A.h[e] = 0.0; Bc.h[e] = 0.0; A.ax[0][e] = A.ax[1][e] = A.ax[2][e] = 0.0; Bc.ax[0][e] = Bc.ax[1][e] = Bc.ax[2][e] = 0.0; }
+            A.rad = Bc.rad = A.margin = Bc.margin = A.rho = Bc.rho = 0.0;
             if (live && !(m.dbg & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
@@ -2005,88 +1953,28 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 if (verdict == 1) mark_hit(b, mask_bits, mask_bytes);
                 pooled = verdict < 0;
             }
-            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pooled);
-            if (bal != 0ull) {
-                int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&pool_n, __builtin_popcountll(bal));
-                wbase = __builtin_amdgcn_readfirstlane(wbase);
-                if (pooled) {
-                    const int slot = wbase + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                    if (POOL_CAP >= NARROW_T || slot < POOL_CAP) pool_put<POOL_CAP>(pool, slot, A, Bc, tc, b);
-                    else {
-                        // pool full (more survivors in this chunk than the pool was sized for): decide in place
-                        const bool hit = (BOOL_ONLY || tc == 0.0) ? gjk_intersect(A, Bc) : gjk_collides(A, Bc, tc);
-                        if (hit) mark_hit(b, mask_bits, mask_bytes);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        NBK_STAMP(5);
-        // ---- phase 2 -----------------------------------------------------------------------------------------------
-        {
-            const int np = (m.dbg & 8) ? 0 : (pool_n < POOL_CAP ? pool_n : POOL_CAP);
-            bool have = false;
-            Core A, Bc;
-            GjkBool gb;
-            double tc = 0.0;
-            long long b = 0;
-            A.kind = K_POINT; Bc.kind = K_POINT;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) { A.c[e] = 0.0; Bc.c[e] = 1.0; A.h[e] = 0.0; Bc.h[e] = 0.0; A.ax[0][e] = A.ax[1][e] = A.ax[2][e] = 0.0; Bc.ax[0][e] = Bc.ax[1][e] = Bc.ax[2][e] = 0.0; }
-            A.rad = Bc.rad = A.margin = Bc.margin = A.rho = Bc.rho = 0.0;
-            gjkb_init(gb, A, Bc);
+            NBK_STAMP(5);
+            // ---- phase 2: the undecided lanes walk GJK on their own item, one iteration per trip ---------------------------
+            // (a chunk has at most 64 undecided items and 64 lanes: nothing to redistribute, so no pool)
+            bool have = pooled && !(m.dbg & 8);
             if constexpr (BOOL_ONLY) {
-                while (true) {
-                    // idle lanes take the next pooled items (one LDS atomic per wave and trip)
-                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
-                    if (idle != 0ull) {
-                        int first = 0;
-                        if (lane == 0) first = atomicAdd(&pool_next, __builtin_popcountll(idle));
-                        first = __builtin_amdgcn_readfirstlane(first);
-                        if (!have) {
-                            const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                            if (slot < np) {
-                                pool_get<POOL_CAP>(pool, slot, A, Bc, tc, b);
-                                gjkb_init(gb, A, Bc);
-                                have = true;
-                            }
-                        }
-                    }
-                    if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+                GjkBool gb;
+                gjkb_init(gb, A, Bc);
+                while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
                         const int r = gjkb_step(gb, A, Bc);
-                        if (r != 0) {
-                            if (r == 2) mark_hit(b, mask_bits, mask_bytes);
-                            have = false;
-                        }
+                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
             } else {
+                GjkBool gb;
                 GjkPred g;
+                gjkb_init(gb, A, Bc);
                 gjk_pred_init(g, A, Bc);
-                while (true) {
-                    const unsigned long long idle = __builtin_amdgcn_ballot_w64(!have);
-                    if (idle != 0ull) {
-                        int first = 0;
-                        if (lane == 0) first = atomicAdd(&pool_next, __builtin_popcountll(idle));
-                        first = __builtin_amdgcn_readfirstlane(first);
-                        if (!have) {
-                            const int slot = first + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
-                            if (slot < np) {
-                                pool_get<POOL_CAP>(pool, slot, A, Bc, tc, b);
-                                if (tc == 0.0) gjkb_init(gb, A, Bc); else gjk_pred_init(g, A, Bc);
-                                have = true;
-                            }
-                        }
-                    }
-                    if (__builtin_amdgcn_ballot_w64(have) == 0ull) break;
+                while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
                         const int r = (tc == 0.0) ? gjkb_step(gb, A, Bc) : gjk_pred_step(g, A, Bc, tc);
-                        if (r != 0) {
-                            if (r == 2) mark_hit(b, mask_bits, mask_bytes);
-                            have = false;
-                        }
+                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
             }
@@ -2109,22 +1997,16 @@ __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(Dev
                                                       const unsigned long long* __restrict__ q_items,
                                                       const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
-    __shared__ double pool[POOL_E * POOL_CAP_BOOL];
-    __shared__ int pool_n, pool_next;
-    // the staged q rows (NARROW_T * n_q doubles) live in the pool's memory: the wave has left the FK replay, the last reader
-    // of q, before its first pool_put (one wave per workgroup) -- 18.4 KB of LDS per workgroup, 8 workgroups per CU
-    static_assert(POOL_E * POOL_CAP_BOOL >= NARROW_T * NBK_MAX_DOF, "q rows must fit the pool");
-    narrow_body<true, POOL_CAP_BOOL>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, pool, pool_n, pool_next);
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
+    narrow_body<true>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
 }
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                  const unsigned long long* __restrict__ q_items,
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
-    __shared__ double pool[POOL_E * NARROW_T];
-    __shared__ int pool_n, pool_next;
-    static_assert(POOL_E * NARROW_T >= NARROW_T * NBK_MAX_DOF, "q rows must fit the pool");
-    narrow_body<false, NARROW_T>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, pool, pool, pool_n, pool_next);
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
+    narrow_body<false>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses;
@@ -3110,7 +2992,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         else
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        const size_t nlds = 0;
+        const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q;
         if (threshold == 0.0 && m->margins_zero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * 32), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         else
