@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for every step's mask all-gather before the next step's kernels "
+                    "(default: the gather of step k overlaps the kernels of step k+1; everything completes inside the timed region)")
     args = ap.parse_args()
 
     import torch
@@ -71,15 +73,39 @@ def main():
     q = torch.from_numpy(q_host).cuda()
     n_words = (hi - lo + 63) // 64
     gathered = torch.zeros((world * n_words,), dtype=torch.int64, device="cuda") if world > 1 else None
+    # N > 1: the all-gather of a step's packed mask (a latency-bound 125 KB-per-rank message) runs on RCCL's stream while the
+    # next step's kernels run; two receive buffers, a buffer is waited for before it is reused and all of them before the
+    # clock stops.  gloo (control-flow rehearsal only) and --sync-gather keep the serial form.
+    overlap = world > 1 and args.backend == "nccl" and not args.sync_gather
+    bufs = [gathered, torch.zeros_like(gathered)] if overlap else None
+    pending = [None, None]
+    counter = [0]
+
+    def gather(words):
+        if not overlap:
+            allgather_mask_words(words, gathered)
+            return
+        i = counter[0] & 1
+        counter[0] += 1
+        if pending[i] is not None:
+            pending[i].wait()
+        pending[i] = dist.all_gather_into_tensor(bufs[i], words.contiguous(), async_op=True)
+
+    def drain():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     def step():
         words = dev.validity(q, 0.0, packed=True)
         if world > 1:
-            allgather_mask_words(words, gathered)
+            gather(words)
         return words
 
     for _ in range(args.warmup):
         words = step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -91,7 +117,8 @@ def main():
         words = dev.validity(q, 0.0, packed=True)
         ev[k][1].record()
         if world > 1:
-            allgather_mask_words(words, gathered)
+            gather(words)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -207,6 +234,7 @@ def main():
                                f"{B} q per GPU per step, threshold 0, packed bit mask"
                                + (", RCCL all-gather of mask words" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
+                   "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if overlap else "serial")),
                    "arithmetic": "every verdict is decided in float64 (bit-exact vs the CPU oracle); the broadphase culls in float32 with a slack that only lets it cull what float64 would"},
         "roofline": roofline, "fk_roofline": fk_roofline, "fk_all_links_roofline": fk_all_roofline, "cpu_baseline": cpu,
         "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",

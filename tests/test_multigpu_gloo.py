@@ -119,6 +119,42 @@ def test_sharded_edges_and_records_gloo(fresh_world):
         assert rec.shape == (M, 2) and np.array_equal(rec[:, 0], d) and np.array_equal(rec[:, 1].astype(np.int32), idx)
 
 
+def _worker_async(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bufs = [torch.zeros(world * 4, dtype=torch.int64), torch.zeros(world * 4, dtype=torch.int64)]
+        pending = [None, None]
+        got = []
+        for k in range(5):                      # the double-buffered overlap of bench.py, on CPU tensors
+            i = k & 1
+            if pending[i] is not None:
+                pending[i].wait()
+                got.append(bufs[i].clone())
+            words = torch.full((4,), 100 * k + rank, dtype=torch.int64)
+            pending[i] = dist.all_gather_into_tensor(bufs[i], words, async_op=True)
+        for i in (1, 0):
+            pending[i].wait()
+            got.append(bufs[i].clone())
+        ret[rank] = [g.tolist() for g in got]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gather_pattern_gloo():
+    """bench.py overlaps the all-gather of step k with the kernels of step k+1 (two receive buffers, wait before reuse):
+    the same call pattern on CPU tensors delivers every step's words."""
+    world = 2
+    port = 33500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_async, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        seen = sorted(tuple(x) for x in ret[r])
+        want = sorted(tuple([100 * k + 0] * 4 + [100 * k + 1] * 4) for k in range(5))
+        assert seen == want
+
+
 def test_shard_bounds_cover_and_align():
     from numbotics_amd.parallel import shard_bounds
     for total in (0, 1, 63, 64, 65, 1000, 10_000_000):
