@@ -2921,7 +2921,7 @@ static inline size_t collide_lds(const nbk_model* m) {
 }
 
 // ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
-static const int64_t TWO_KERNEL_MIN_B = 8192;
+static const int64_t TWO_KERNEL_MIN_B = getenv("NBK_TWO_KERNEL_MIN_B") ? atoll(getenv("NBK_TWO_KERNEL_MIN_B")) : 8192;
 static const size_t WS_MAX_BYTES = size_t(1) << 30;
 static const size_t WS_COUNTERS = NSUB * CNT_STRIDE * 8;      // NSUB counters, one cache line each
 static inline size_t ws_header(const nbk_model* m) {           // counters | per-call float32 broadphase tables
