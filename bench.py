@@ -166,6 +166,15 @@ def main():
                 "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_config": 8.0 * chain.dof + 0.125,
                 "note": "VALU-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md",
                 "valu": valu}
+    if valu:
+        # the roof that does bound the step: vector-ALU issue (256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at
+        # 2.4 GHz).  Instruction counts per wave from the SQ pass of the profile the traffic comes from, time from this run.
+        step_k = [k for k in ("k_broad_f32", "k_broad_reg", "k_broad", "k_narrow") if k in valu]
+        insts = sum(valu[k]["valu_insts_per_wave"] * valu[k]["waves"] for k in step_k) * scale
+        peak = 1024 * 2.4e9 / 4.0
+        roofline["valu_issue"] = {"bound": "valu", "achieved": insts / (kern_ms * 1e-3), "peak": peak, "unit": "wave-instructions/s",
+                                  "frac": insts / (kern_ms * 1e-3) / peak, "wave_instructions_per_step": insts,
+                                  "wave_instructions_per_config": insts / (hi - lo), "kernels": step_k}
 
     # ---- the HBM-bound kernel of the path: pose-writing FK of one frame -------------------------------
     T = arm.forward_kinematics(q, "tool_frame")
