@@ -39,6 +39,34 @@ with tempfile.TemporaryDirectory() as d:
             nbad = int((ref != got).sum())
             bad += nbad; total += B
             line += f" | thr {thr:g}: frac {ref.mean():.3f} mismatches {nbad}"
+        if os.environ.get("NBK_FUZZ_ALL"):
+            # every other entry point, bit for bit
+            def same(a, b):
+                a, b = np.asarray(a), np.asarray(b)
+                return a.shape == b.shape and bool(((a.view(np.int64) == b.view(np.int64)) | (np.isnan(a) & np.isnan(b))).all()) if a.dtype == np.float64 else bool(np.array_equal(a, b))
+            n = 1500
+            dist_, w, rows = arm.proximity_jacobians(q[:n])
+            dr, wr, rr = orc.proximity_jacobian(q[:n])
+            dmin, idx = arm.closest_distance(q[:n])
+            dref, iref = orc.closest(q[:n])
+            _, dev = arm._scene_device()
+            ok, end, ns = dev.edge_validity(q[:400], q[400:800], 0.03, 1.5, mode="steer")
+            okr, endr, nsr = orc.edge_validity(q[:400], q[400:800], 0.03, 1.5, mode="steer", nthreads=16)
+            checks = {"dist": same(dist_, dr), "wit": same(w, wr), "rows": same(rows, rr), "closest": same(dmin, dref) and same(idx, iref),
+                      "edges": same(ok, okr) and same(ns, nsr) and same(end, endr)}
+            frame = list(arm._kin.frames)[-1]
+            orc_k = Oracle(arm._kin)
+            checks["fk"] = same(arm.forward_kinematics(q[:n], frame), orc_k.fk(q[:n], frame))
+            if len(arm._kin.frames[frame].path):
+                checks["jac"] = same(arm.jacobian(q[:n], frame), orc_k.jacobian(q[:n], frame))
+                pose = orc_k.fk(q[:n], frame)
+                q0 = q[:n] + rng.uniform(-0.3, 0.3, (n, chain.dof))
+                r1 = arm._kin_device().ik(pose, q0, frame)
+                r2 = orc_k.ik(pose, q0, frame)
+                checks["ik"] = same(r1[0], r2[0]) and same(r1[1], r2[1]) and same(r1[3], r2[3])
+            nb = sum(0 if v else 1 for v in checks.values())
+            bad += nb
+            line += " | " + " ".join(f"{k}:{'ok' if v else 'MISMATCH'}" for k, v in checks.items())
         print(line, flush=True)
 print(f"TOTAL configurations checked {total}, mismatches {bad}")
 sys.exit(1 if bad else 0)
