@@ -66,6 +66,8 @@ struct DevModel {
     const float* f_tab;
     int f_trans, f_slide, f_base, f_tl, f_wc;
     float f_eps, f_reach;
+    const double* bq_static;      // [P] (broadphase order) static lower bound of the pair's centre distance (plane: height) minus the
+                                  //     bounding radii, over ALL configurations: reach of the shape's centre from the base; -inf when unknown
     const int4* vp_info;          // [P] canonical refs and their joint masks in one 16-byte record: ra, rb, mask(ra), mask(rb)
     int bq_count[4];              // pairs per broadphase category
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
@@ -1083,6 +1085,10 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
             rp[lo * 16 + hi] = p;
         } else {
             const int w = bt[1];
+            // static reach culling: this world shape is out of the shape's reach for this threshold, whatever q is
+            const double sl = m.bq_static[j];
+            const double tcut = cat == 0 ? thr + cst[0] : (thr + cst[0]) + cst[1];
+            if (sl - 1e-9 * (1.0 + __builtin_fabs(sl)) >= tcut) continue;
             float key;
             if (cat == 0) { const double tt = thr + cst[0]; key = (float)tt + __builtin_fabsf((float)tt) * 2.4e-7f; }
             else {
@@ -1719,7 +1725,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
         if (wk == K_PLANE) {
 #pragma unroll
             for (int a = 0; a < S; ++a) {
-                if (a < m.n_rshapes) {
+                if (a < m.n_rshapes && tab_wp[w * 16 + a] >= 0) {          // uniform: not a pair, or out of reach for good
                     const float key = tab_wkey[w * 16 + a];
                     const float rhoA = tab_rho[a];
                     const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
@@ -1731,7 +1737,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
         } else if (wk == K_BOX) {
 #pragma unroll
             for (int a = 0; a < S; ++a) {
-                if (a < m.n_rshapes) {
+                if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
                     const float rs = tab_wkey[w * 16 + a];
                     const float tc = tab_wtc[w * 16 + a];
                     const float rho = tab_rho[a];
@@ -1765,7 +1771,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
         } else {
 #pragma unroll
             for (int a = 0; a < S; ++a) {
-                if (a < m.n_rshapes) {
+                if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
                     const float rs = tab_wkey[w * 16 + a];
                     const float r = rs + e2;
                     const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
@@ -2607,6 +2613,43 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
                 ++cur_b;
             }
     }
+    // static reach culling: the centre of robot shape a never leaves the ball of radius reach_a around the base origin
+    // (sum of the joint offsets on its path + its local offset; unbounded when a prismatic joint is on the path), so a world
+    // shape farther than that from the base, radii included, can never be a candidate.  Rigorous by the triangle inequality.
+    std::vector<double> bq_static((size_t)(P > 0 ? P : 1), -INFINITY);
+    {
+        std::vector<double> reach(S > 0 ? S : 1, 0.0);
+        for (int i = 0; i < S; ++i) {
+            const int f = d->rshape_frame[order[i]];
+            double r = 0.0;
+            bool unbounded = false;
+            if (f >= 0)
+                for (int k = 0; k < J; ++k)
+                    if ((frame_mask[f] >> k) & 1u) {
+                        if (d->joint_type[k] == NBK_PRISMATIC) unbounded = true;
+                        r += std::sqrt(d->joint_trans[3 * k] * d->joint_trans[3 * k] + d->joint_trans[3 * k + 1] * d->joint_trans[3 * k + 1] +
+                                       d->joint_trans[3 * k + 2] * d->joint_trans[3 * k + 2]);
+                    }
+            const double lx = rs_local[12 * i + 3], ly = rs_local[12 * i + 7], lz = rs_local[12 * i + 11];
+            r += std::sqrt(lx * lx + ly * ly + lz * lz);
+            reach[i] = unbounded ? INFINITY : r * (1.0 + 1e-12) + 1e-12;
+        }
+        const double b0[3] = {d->base_pose[3], d->base_pose[7], d->base_pose[11]};
+        for (int j = 0; j < P; ++j) {
+            const int cat = bq_tab[4 * j + 3];
+            if (cat == 1) continue;
+            const int a = bq_tab[4 * j] / 3, w = bq_tab[4 * j + 1], i = bq_tab[4 * j + 2];
+            const double* wc = &ws_core[18 * (size_t)w];
+            if (!(reach[a] < INFINITY)) continue;
+            if (cat == 0) {
+                const double hb = wc[9] * (b0[0] - wc[0]) + wc[10] * (b0[1] - wc[1]) + wc[11] * (b0[2] - wc[2]);
+                bq_static[j] = hb - reach[a] - vp_cst[4 * i + 2];
+            } else {
+                const double dx = wc[0] - b0[0], dy = wc[1] - b0[1], dz = wc[2] - b0[2];
+                bq_static[j] = std::sqrt(dx * dx + dy * dy + dz * dz) - reach[a] - (vp_cst[4 * i + 2] + vp_cst[4 * i + 3]);
+            }
+        }
+    }
     if (3 * S >= 65536 || W >= 65536) return NBK_ERR_UNSUPPORTED;
     if ((size_t)(d->n_q + 12 * slots + 3 * S) * 64 * sizeof(double) + (4 * (size_t)P + 18 * (size_t)W) * sizeof(double) + BQ_CAP * 4 > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     if (P >= (1 << 20)) return NBK_ERR_UNSUPPORTED;
@@ -2619,7 +2662,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     Blob B;
     nbk_model* M = new nbk_model();
     memset(&M->d, 0, sizeof(M->d));
-    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi, ft; } o;
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi, ft, bs; } o;
     o.jt = B.add(d->joint_type, sizeof(int) * J);
     o.jq = B.add(d->joint_qidx, sizeof(int) * J);
     o.jl = B.add(load.data(), sizeof(int) * J);
@@ -2696,6 +2739,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     for (int i = 0; i < S; ++i) rs_frame_v[i] = d->rshape_frame[order[i]];
     o.rf = B.add(rs_frame_v.data(), sizeof(int) * S);
     o.bt = B.add(bq_tab.data(), sizeof(int) * 4 * P);
+    o.bs = B.add(bq_static.data(), sizeof(double) * P);
     B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
 
     void* dev = nullptr;
@@ -2745,6 +2789,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     }
     m.rs_frame = reinterpret_cast<const int*>(base + o.rf);
     m.bq_tab = reinterpret_cast<const int*>(base + o.bt);
+    m.bq_static = reinterpret_cast<const double*>(base + o.bs);
     for (int c = 0; c < 4; ++c) { m.bq_count[c] = 0; }
     for (int i = 0; i < P; ++i) m.bq_count[bq_tab[4 * i + 3]]++;
     { const char* ab = getenv("NBK_ABLATE"); m.dbg = ab ? atoi(ab) : 0; }
