@@ -98,6 +98,7 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
+    bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
     bool margins_zero;        // every pair that can reach GJK (no point core, not point/segment x point/segment) has mA = mB = 0:
                               // with threshold 0 its contact threshold tc is exactly 0 and the boolean walk decides it
     // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
@@ -2651,7 +2652,10 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         }
     }
     if (3 * S >= 65536 || W >= 65536) return NBK_ERR_UNSUPPORTED;
-    if ((size_t)(d->n_q + 12 * slots + 3 * S) * 64 * sizeof(double) + (4 * (size_t)P + 18 * (size_t)W) * sizeof(double) + BQ_CAP * 4 > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    // the LDS broadphase (robots with more than 16 primitives) keeps the pair constants and world cores in LDS; robots the
+    // register broadphases serve do not need it, however many world shapes there are
+    const bool lds_broad_ok = (size_t)(d->n_q + 12 * slots + 3 * S) * 64 * sizeof(double) + (4 * (size_t)P + 18 * (size_t)W) * sizeof(double) + BQ_CAP * 4 <= 160 * 1024;
+    if (!lds_broad_ok && S > 16) return NBK_ERR_UNSUPPORTED;
     if (P >= (1 << 20)) return NBK_ERR_UNSUPPORTED;
     // LDS budget: q rows + shape rows + saved frames, 512 B each (+ queue and flags of the validity path);
     // the raw q slab reuses the shape area
@@ -2799,6 +2803,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     M->margins_zero = margins_zero;
+    M->lds_broad_ok = lds_broad_ok;
     (void)hipGetDevice(&M->device);
     *out = M;
     return NBK_OK;
@@ -3012,8 +3017,8 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         uint64_t* mb = mask_bits ? mask_bits + b0 / 64 : nullptr;
         uint8_t* my = mask_bytes ? mask_bytes + b0 : nullptr;
         const int S = m->d.n_rshapes;
-        const bool use_reg = S <= 16 && !getenv("NBK_NO_REG_BROAD");
-        const bool f32 = !getenv("NBK_F64_BROAD");
+        const bool use_reg = S <= 16 && (!getenv("NBK_NO_REG_BROAD") || !m->lds_broad_ok);
+        const bool f32 = !getenv("NBK_F64_BROAD") || broad_reg_lds(m, S <= 8 ? 8 : (S <= 12 ? 12 : 16)) > 160 * 1024;   // the float64 form keeps its tables in LDS
         float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
         const size_t qrows_f = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);

@@ -806,6 +806,32 @@ def test_non_finite_joint_values_count_as_colliding(fresh_world, torch_cuda):
     assert np.array_equal(ok[finite], okr[finite]) and not ok[~finite].any() and not okr[~finite].any()
 
 
+def test_scene_with_hundreds_of_obstacles(fresh_world, torch_cuda):
+    """400 world shapes (4 444 pairs): the register broadphase reads its per-call tables from global memory, so the number
+    of obstacles is not bounded by LDS; most of them are out of reach and dropped per call by the static reach test."""
+    from numbotics_amd.physics import GraphChain
+    from numbotics_amd.robots import Arm
+    from random_scenes import random_obstacles
+    from conftest import URDF
+    chain = GraphChain.from_urdf(URDF)
+    arm = Arm(chain)
+    rng = np.random.default_rng(31)
+    obs = random_obstacles(rng, 400, reach=2.5)
+    sm = arm.scene_model()
+    assert sm.n_wshapes == 400 and sm.n_pairs > 4000
+    orc = Oracle(sm)
+    q = sample_q(chain, 12000, seed=33)
+    for thr in (0.0, 0.02):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref)
+        assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])          # fused kernel
+    assert 0.05 < orc.validity(q, 0.0, nthreads=8).mean() < 0.95
+    dmin, idx = arm.closest_distance(q[:300])
+    dref, iref = orc.closest(q[:300])
+    assert_bitwise(dmin, dref, "closest among 4444 pairs")
+    assert np.array_equal(idx, iref)
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
