@@ -2986,9 +2986,13 @@ static inline size_t broad_lds(const nbk_model* m) {
 // configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
 static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
     const int64_t P = m->n_pairs > 0 ? m->n_pairs : 1;
-    int64_t t = (int64_t)((WS_MAX_BYTES - ws_header(m)) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
+    // scenes with many pairs get up to 8 GiB (of 288 GB) so that a tile still fills the chip
+    const size_t ws_max = P > 512 ? (size_t(8) << 30) : WS_MAX_BYTES;
+    int64_t t = (int64_t)((ws_max - ws_header(m)) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
     t = (t / WAVE) * WAVE;
-    if (t < WAVE) t = WAVE;
+    // never less than two blocks per sub-queue: scenes with thousands of pairs get a workspace above WS_MAX_BYTES instead
+    // of tiles too small to fill the chip (288 GB of HBM: 3 GB for 11 000 pairs)
+    if (t < 2 * (int64_t)NSUB * WAVE) t = 2 * (int64_t)NSUB * WAVE;
     return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
 }
 
@@ -3043,10 +3047,13 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
         const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q;
+        // workgroups per sub-queue: one 64-item chunk each at a few survivors per configuration; more chunks are strided over
+        unsigned parts = 4u * nblk / NSUB;
+        parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
         if (threshold == 0.0 && m->margins_zero)
-            hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * 32), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+            hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         else
-            hipLaunchKernelGGL(k_narrow, dim3(NSUB * 32), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+            hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         NBK_HIP(hipGetLastError());
     }
     return NBK_OK;
