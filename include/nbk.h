@@ -31,7 +31,8 @@ enum {
     NBK_ERR_INVALID = -1,      /* bad argument (null pointer, negative size, bad index) */
     NBK_ERR_NO_DEVICE = -2,    /* no HIP device / not a gfx950 code object for this device */
     NBK_ERR_HIP = -3,          /* a HIP runtime call failed; see nbk_last_error() */
-    NBK_ERR_UNSUPPORTED = -4,  /* descriptor exceeds a compiled-in limit */
+    NBK_ERR_UNSUPPORTED = -4,  /* descriptor exceeds a compiled-in limit (32 joints / DoF, 2^20 pairs, LDS capacity), or this
+                                  entry point cannot serve this descriptor (per-pair distances of robots with 30+ primitives) */
     NBK_ERR_ALLOC = -5
 };
 

@@ -98,6 +98,7 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
+    bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
     bool margins_zero;        // every pair that can reach GJK (no point core, not point/segment x point/segment) has mA = mB = 0:
                               // with threshold 0 its contact threshold tc is exactly 0 and the boolean walk decides it
@@ -2660,7 +2661,10 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     // LDS budget: q rows + shape rows + saved frames, 512 B each (+ queue and flags of the validity path);
     // the raw q slab reuses the shape area
     const size_t lds_bytes = (size_t)(d->n_q + (rows > d->n_q ? rows : d->n_q) + 12 * slots) * 64 * sizeof(double) + VALIDITY_LDS_EXTRA;
-    if (lds_bytes > 160 * 1024) return NBK_ERR_UNSUPPORTED;
+    // robots whose primitives do not fit the LDS-parked layout (some 25+ shapes) keep validity and edges, through the
+    // broadphase + narrowphase kernels at every batch size; the per-pair distance entry points report UNSUPPORTED for them
+    const bool parked_ok = lds_bytes <= 160 * 1024;
+    if (S <= 16 && (size_t)d->n_q * 64 * sizeof(double) + 12 * (size_t)slots * 64 * sizeof(float) + 4096 > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     if (P >= (1 << 26)) return NBK_ERR_UNSUPPORTED;
 
     Blob B;
@@ -2804,6 +2808,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     M->margins_zero = margins_zero;
     M->lds_broad_ok = lds_broad_ok;
+    M->parked_ok = parked_ok;
     (void)hipGetDevice(&M->device);
     *out = M;
     return NBK_OK;
@@ -3066,7 +3071,7 @@ static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
 
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
     if (m == nullptr || B < 0) return NBK_ERR_INVALID;
-    if (B < TWO_KERNEL_MIN_B || m->n_pairs == 0) return 0;
+    if ((B < TWO_KERNEL_MIN_B && m->parked_ok) || m->n_pairs == 0 || B == 0) return 0;
     // NSUB sub-queues, each sized for the blocks that map to it (rounded up)
     return two_kernel_workspace_bytes(m, B);
 }
@@ -3079,6 +3084,7 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
     const int64_t need = nbk_validity_workspace_bytes(m, B);
     if (need == 0 || workspace == nullptr || workspace_bytes < need) {
         if (need != 0 && workspace != nullptr) return NBK_ERR_INVALID;       // a workspace was given but is too small
+        if (!m->parked_ok) return need != 0 ? NBK_ERR_INVALID : NBK_ERR_UNSUPPORTED;   // this robot needs the workspace path
         hipLaunchKernelGGL(k_validity, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), st, m->d, q, B, threshold, mask_bits, mask_bytes);
         NBK_HIP(hipGetLastError());
         return NBK_OK;
@@ -3104,6 +3110,7 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
 
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || min_dist == nullptr))) return NBK_ERR_INVALID;
+    if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0) return NBK_OK;
     static const bool brute = getenv("NBK_CLOSEST_BRUTE") != nullptr;
     if (brute)
@@ -3119,6 +3126,7 @@ int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double
 
 int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr))) return NBK_ERR_INVALID;
+    if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     if (witness != nullptr)
         hipLaunchKernelGGL(k_distances<2>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
@@ -3133,6 +3141,7 @@ int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B,
 int32_t nbk_proximity_jacobian_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, double* jrows,
                                      void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr || witness == nullptr || jrows == nullptr))) return NBK_ERR_INVALID;
+    if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     const size_t lds = collide_lds(m) + sizeof(double) * WAVE * 6 * (size_t)m->n_joints;
     if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
@@ -3152,7 +3161,7 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
     if (E == 0) return NBK_OK;
     if (E > 0x7fffffffLL) return NBK_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (E < EDGE_BATCH_MIN_E || m->n_pairs == 0) {
+    if ((E < EDGE_BATCH_MIN_E && m->parked_ok) || m->n_pairs == 0) {
         // a handful of edges: one wave per edge, early exit, one launch
         hipLaunchKernelGGL(k_edges, dim3((unsigned)E), dim3(WAVE), collide_lds(m), st, m->d, starts, goals, dist, E,
                            resolution, max_distance, mode, threshold, valid, end, n_samples);

@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def random_urdf(rng, n_links, path):
+def random_urdf(rng, n_links, path, max_back=3):
     """A random tree of n_links links: revolute / continuous / prismatic / fixed joints with random origins and
     axes, every link carrying 0-2 collision primitives (box / sphere / cylinder / capsule)."""
     def geom():
@@ -27,7 +27,7 @@ def random_urdf(rng, n_links, path):
                        for _ in range(int(rng.choice([0, 1, 1, 1, 2]))))
         out.append(f'<link name="l{i}">{cols}</link>')
     for i in range(1, n_links):
-        parent = int(rng.integers(max(0, i - 3), i))
+        parent = int(rng.integers(max(0, i - max_back), i))
         jt = str(rng.choice(["revolute", "revolute", "continuous", "prismatic", "fixed"]))
         ax = rng.normal(size=3)
         ax /= np.linalg.norm(ax)

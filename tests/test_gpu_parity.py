@@ -832,6 +832,40 @@ def test_scene_with_hundreds_of_obstacles(fresh_world, torch_cuda):
     assert np.array_equal(idx, iref)
 
 
+def test_robot_with_forty_primitives(fresh_world, torch_cuda, tmp_path):
+    """More primitives than the LDS-parked kernels can hold: validity (every batch size) and edges still run, through the
+    broadphase + narrowphase kernels; the per-pair distance entry points say UNSUPPORTED instead of failing a launch."""
+    from numbotics_amd.physics import GraphChain
+    from numbotics_amd.robots import Arm
+    from numbotics_amd._lib import NbkError
+    from random_scenes import random_urdf, random_obstacles
+    rng = np.random.default_rng(124)
+    chain = GraphChain.from_urdf(random_urdf(rng, 36, str(tmp_path / "big.urdf"), max_back=1))       # a 36-link serial chain, 39 primitives
+    arm = Arm(chain)
+    obs = random_obstacles(rng, 3)
+    sm = arm.scene_model()
+    assert sm.n_rshapes >= 25
+    orc = Oracle(sm)
+    lim = np.asarray(chain.joint_limits, dtype=np.float64)
+    lim = np.where(np.isfinite(lim), lim, np.sign(lim) * np.pi)
+    q = rng.uniform(lim[:, 0], lim[:, 1], (9000, chain.dof))
+    for thr in (0.0, 0.01):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref)
+        assert np.array_equal(arm.in_collision(q[:100], thr), ref[:100])         # small batch: same kernels
+        assert bool(arm.in_collision(q[7], thr)) == bool(ref[7])                   # scalar contract
+    _, dev = arm._scene_device()
+    for n_e in (5, 200):
+        ok, end, ns = dev.edge_validity(q[:n_e], q[n_e:2 * n_e], 0.05, 1.0, mode="steer")
+        okr, endr, nsr = orc.edge_validity(q[:n_e], q[n_e:2 * n_e], 0.05, 1.0, mode="steer")
+        assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
+        assert_bitwise(end, endr, "big robot edge ends")
+    with pytest.raises(NbkError):
+        arm.pair_distances(q[:10])
+    with pytest.raises(NbkError):
+        arm.closest_distance(q[:10])
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
