@@ -866,6 +866,28 @@ def test_robot_with_forty_primitives(fresh_world, torch_cuda, tmp_path):
         arm.closest_distance(q[:10])
 
 
+def test_misaligned_views_and_extreme_thresholds(fresh_world, torch_cuda):
+    """Device views that start on an odd row (8-byte but not 16-byte aligned slabs), and thresholds far outside the
+    geometry (everything / nothing collides): same masks as the oracle on every path."""
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    q = sample_q(chain, 20001, seed=95)
+    qt = torch_cuda.from_numpy(q).cuda()
+    ref = orc.validity(q, 0.0, nthreads=8)
+    for lo, hi in ((1, 20001), (3, 9003), (1, 4001), (5, 70)):
+        view = qt[lo:hi]
+        assert view.data_ptr() % 16 != 0 or lo % 2 == 0
+        got = arm.in_collision(view, 0.0)
+        assert np.array_equal(got.cpu().numpy(), ref[lo:hi]), (lo, hi)
+    T = arm.forward_kinematics(qt[1:3001], "tool_frame")
+    assert_bitwise(T.cpu().numpy(), Oracle(arm._kin).fk(q[1:3001], "tool_frame"), "fk on a misaligned view")
+    for thr in (1e6, -1e6, 5.0, -5.0):
+        want = orc.validity(q[:9000], thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q[:9000], thr), want), thr
+        assert np.array_equal(arm.in_collision(q[:2000], thr), want[:2000]), thr
+        assert want.all() if thr > 0 else not want.any()
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
