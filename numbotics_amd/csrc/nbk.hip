@@ -98,6 +98,7 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
+    std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
     bool margins_zero;        // every pair that can reach GJK (no point core, not point/segment x point/segment) has mA = mB = 0:
@@ -1849,7 +1850,9 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
 __device__ unsigned long long g_narrow_prof[16];
 #define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
 
-template <bool BOOL_ONLY>
+// MODE 0: both walks (tc == 0 picks the boolean one per item), 1: boolean walk only, 2: distance predicate only (the host has
+// established tc != 0 for every pair that can reach GJK: a non-zero threshold such as IRIS' 1e-6)
+template <int MODE>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
                          const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
                          unsigned long long cap, uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
@@ -1965,12 +1968,21 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             // ---- phase 2: the undecided lanes walk GJK on their own item, one iteration per trip ---------------------------
             // (a chunk has at most 64 undecided items and 64 lanes: nothing to redistribute, so no pool)
             bool have = pooled && !(m.dbg & 8);
-            if constexpr (BOOL_ONLY) {
+            if constexpr (MODE == 1) {
                 GjkBool gb;
                 gjkb_init(gb, A, Bc);
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
                         const int r = gjkb_step(gb, A, Bc);
+                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
+                    }
+                }
+            } else if constexpr (MODE == 2) {
+                GjkPred g;
+                gjk_pred_init(g, A, Bc);
+                while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
+                    if (have) {
+                        const int r = gjk_pred_step(g, A, Bc, tc);
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
@@ -2006,7 +2018,7 @@ __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(Dev
                                                       const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    narrow_body<true>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+    narrow_body<1>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
 }
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
@@ -2014,7 +2026,15 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, 
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    narrow_body<false>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+    narrow_body<0>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+}
+
+__global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pred(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+                                                      const unsigned long long* __restrict__ q_items,
+                                                      const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
+    narrow_body<2>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses;
@@ -2573,6 +2593,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     std::vector<int> vp_tab(4 * (size_t)P), vp_canon(2 * (size_t)P);
     std::vector<double> vp_cst(4 * (size_t)P), ws_center(3 * (size_t)W);
     bool margins_zero = true;
+    std::vector<double> gjk_margins;
     for (int i = 0; i < P; ++i) {
         const int p = vorder[i];
         const int ka = kind_of(refA[p]), kb = kind_of(refB[p]);
@@ -2589,6 +2610,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
             const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;          // canonical order
             const bool closed = k0 == K_POINT || ((k0 == K_POINT || k0 == K_SEG) && (k1 == K_POINT || k1 == K_SEG));
             if (k1 != K_PLANE && !closed && (ca[4] != 0.0 || cb[4] != 0.0)) margins_zero = false;
+            if (k1 != K_PLANE && !closed) { gjk_margins.push_back(ca[4]); gjk_margins.push_back(cb[4]); }
         }
     }
     for (int w = 0; w < W; ++w) { ws_center[3 * w] = ws_core[18 * w]; ws_center[3 * w + 1] = ws_core[18 * w + 1]; ws_center[3 * w + 2] = ws_core[18 * w + 2]; }
@@ -2807,6 +2829,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     M->margins_zero = margins_zero;
+    M->gjk_margins = gjk_margins;
     M->lds_broad_ok = lds_broad_ok;
     M->parked_ok = parked_ok;
     (void)hipGetDevice(&M->device);
@@ -3055,8 +3078,16 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         // workgroups per sub-queue: one 64-item chunk each at a few survivors per configuration; more chunks are strided over
         unsigned parts = 4u * nblk / NSUB;
         parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
-        if (threshold == 0.0 && m->margins_zero)
+        // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
+        // distance predicate only, else the build with both
+        bool any_zero = false, any_nonzero = false;
+        for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
+            if ((threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1] == 0.0) any_zero = true; else any_nonzero = true;
+        }
+        if (!any_nonzero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+        else if (!any_zero)
+            hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         else
             hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         NBK_HIP(hipGetLastError());
