@@ -1851,7 +1851,8 @@ __device__ unsigned long long g_narrow_prof[16];
 #define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
 
 // MODE 0: both walks (tc == 0 picks the boolean one per item), 1: boolean walk only, 2: distance predicate only (the host has
-// established tc != 0 for every pair that can reach GJK: a non-zero threshold such as IRIS' 1e-6)
+// established tc != 0 for every pair that can reach GJK), 3: distance predicate with tc > 0 everywhere (a positive threshold
+// such as IRIS' 1e-6: no overlap-depth estimate is ever needed)
 template <int MODE>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
                          const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
@@ -1977,12 +1978,12 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
-            } else if constexpr (MODE == 2) {
+            } else if constexpr (MODE == 2 || MODE == 3) {
                 GjkPred g;
                 gjk_pred_init(g, A, Bc);
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
-                        const int r = gjk_pred_step(g, A, Bc, tc);
+                        const int r = gjk_pred_step<MODE == 3>(g, A, Bc, tc);
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
@@ -2035,6 +2036,14 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pred(DevModel m, EdgeSrc
                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
     narrow_body<2>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+}
+
+__global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pos(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+                                                     const unsigned long long* __restrict__ q_items,
+                                                     const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                     uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    extern __shared__ double qstage[];          // NARROW_T * n_q doubles
+    narrow_body<3>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses;
@@ -3080,12 +3089,16 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
         // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
         // distance predicate only, else the build with both
-        bool any_zero = false, any_nonzero = false;
+        bool any_zero = false, any_nonzero = false, any_negative = false;
         for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
-            if ((threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1] == 0.0) any_zero = true; else any_nonzero = true;
+            const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
+            if (tc == 0.0) any_zero = true; else any_nonzero = true;
+            if (!(tc > 0.0)) any_negative = true;          // (a NaN threshold counts as not positive)
         }
         if (!any_nonzero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+        else if (!any_zero && !any_negative)
+            hipLaunchKernelGGL(k_narrow_pos, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         else if (!any_zero)
             hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
         else

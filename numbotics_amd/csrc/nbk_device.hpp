@@ -442,6 +442,8 @@ NBK_DEV void gjk_pred_init(GjkPred& g, const Core& A, const Core& Bc) {
     g.it = 0;
 }
 
+// POSITIVE: the caller guarantees tc > 0, which compiles the overlap-depth estimate (needed only for negative tc) out
+template <bool POSITIVE = false>
 NBK_DEV int gjk_pred_step(GjkPred& g, const Core& A, const Core& Bc, double tc) {
     const double tc2 = tc * tc;
     bool finish = g.it >= GJK_MAXIT;       // out of iterations: decide on the current simplex point
@@ -467,9 +469,11 @@ NBK_DEV int gjk_pred_step(GjkPred& g, const Core& A, const Core& Bc, double tc) 
             if (st == 1) {
                 if (g.sep) finish = true;
                 else {
-                    if (tc >= 0.0) return 2;
-                    double nrm[3];
-                    return (-overlap_depth(A, Bc, nrm) < tc) ? 2 : 1;
+                    if (POSITIVE || tc >= 0.0) return 2;
+                    if constexpr (!POSITIVE) {
+                        double nrm[3];
+                        return (-overlap_depth(A, Bc, nrm) < tc) ? 2 : 1;
+                    }
                 }
             } else if (st == 2) finish = true;
             else {
