@@ -2014,6 +2014,37 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     }
 }
 
+// experiment (NBK_SORT_ITEMS): sorts every sub-queue by (pair, configuration) so that the chunks k_narrow takes are
+// pair-homogeneous; one workgroup per sub-queue, up to 4096 items in LDS, bitonic
+__global__ __launch_bounds__(256) void k_sort_items(unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
+                                                     unsigned long long cap) {
+    __shared__ unsigned long long key[4096];
+    const unsigned sub = blockIdx.x;
+    unsigned long long n = q_count[sub * CNT_STRIDE];
+    if (n > cap) n = cap;
+    if (n > 4096ull) n = 4096ull;
+    unsigned long long* it = q_items + (unsigned long long)sub * cap;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        unsigned long long v = ~0ull;
+        if ((unsigned long long)i < n) { const unsigned long long x = it[i]; v = ((x & 0xFFFFFull) << 44) | (x >> 20); }
+        key[i] = v;
+    }
+    __syncthreads();
+    for (int k = 2; k <= 4096; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < 4096; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = key[i], b = key[l];
+                    if ((a > b) == up) { key[i] = b; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; (unsigned long long)i < n; i += 256) { const unsigned long long v = key[i]; it[i] = ((v & 0xFFFFFFFFFFFull) << 20) | (v >> 44); }
+}
+
 __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                       const unsigned long long* __restrict__ q_items,
                                                       const unsigned long long* __restrict__ q_count, unsigned long long cap,
@@ -3089,6 +3120,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
         // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
         // distance predicate only, else the build with both
+        if (getenv("NBK_SORT_ITEMS")) hipLaunchKernelGGL(k_sort_items, dim3(NSUB), dim3(256), 0, st, items, count, cap_sub);
         bool any_zero = false, any_nonzero = false, any_negative = false;
         for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
             const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
