@@ -68,6 +68,8 @@ struct DevModel {
     float f_eps, f_reach;
     const double* bq_static;      // [P] (broadphase order) static lower bound of the pair's centre distance (plane: height) minus the
                                   //     bounding radii, over ALL configurations: reach of the shape's centre from the base; -inf when unknown
+    const int* vp_cls;            // [P] kind class of the pair (0 box-box, 1 box-cylinder, 2 cylinder-cylinder, 3 the rest): queue routing
+    int cls_base[4], cls_groups[4];   // sub-queues [cls_base[c], cls_base[c] + cls_groups[c]) serve class c, in proportion to its pairs
     const int4* vp_info;          // [P] canonical refs and their joint masks in one 16-byte record: ra, rb, mask(ra), mask(rb)
     int bq_count[4];              // pairs per broadphase category
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
@@ -98,6 +100,7 @@ struct nbk_model {
     int n_pairs;
     int n_q;
     int n_joints;
+    int cls_count[4];          // pairs per kind class; cls_groups (in d) sub-queues serve each
     std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
@@ -1028,19 +1031,35 @@ NBK_DEV double readlane_f64(double v, int l) {
 constexpr int NSUB = 256;
 constexpr int CNT_STRIDE = 16;          // one 128-byte line per counter
 
-NBK_DEV void flush_items(unsigned* lds_queue, int qn, int64_t base_cfg, unsigned long long* q_count,
+// Items are routed by the kind class of their pair (vp_cls: box-box, box-cylinder, cylinder-cylinder, the rest):
+// class c owns cls_groups[c] of the NSUB sub-queues (in proportion to its pairs), a block appends to the (block % groups)-th.  The chunks k_narrow takes are then kind-homogeneous -- one core layout, one
+// support routine per side -- which is worth 10 % of its time; one atomicAdd per class present, issued together by lanes 0-3.
+NBK_DEV void flush_items(const DevModel& m, unsigned* lds_queue, int qn, int64_t base_cfg, unsigned long long* q_count,
                          unsigned long long* q_items, unsigned long long cap_sub, int lane) {
     __syncthreads();
-    const unsigned sub = blockIdx.x % NSUB;
-    unsigned long long off = 0;
-    if (lane == 0) off = atomicAdd(q_count + sub * CNT_STRIDE, (unsigned long long)qn);
-    off = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(off >> 32)) << 32) |
-          (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off);
-    unsigned long long* dst = q_items + (unsigned long long)sub * cap_sub;
-    for (int i = lane; i < qn; i += WAVE) {
-        const unsigned it = lds_queue[i];
-        const unsigned long long b = (unsigned long long)(base_cfg + (it & 63u));
-        if (off + i < cap_sub) dst[off + i] = (b << 20) | (unsigned long long)(it >> 6);
+    for (int i0 = 0; i0 < qn; i0 += WAVE) {
+        const int i = i0 + lane;
+        const bool has = i < qn;
+        const unsigned it = has ? lds_queue[i] : 0u;
+        const int cls = has ? m.vp_cls[it >> 6] : 0;
+        unsigned long long bc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bc[c] = __builtin_amdgcn_ballot_w64(has && cls == c);
+        const unsigned long long mine_cnt = lane == 0 ? bc[0] : (lane == 1 ? bc[1] : (lane == 2 ? bc[2] : bc[3]));
+        unsigned long long off = 0;
+        if (lane < 4 && mine_cnt != 0ull)
+            off = atomicAdd(q_count + (size_t)(m.cls_base[lane] + (int)(blockIdx.x % (unsigned)m.cls_groups[lane])) * CNT_STRIDE,
+                            (unsigned long long)__builtin_popcountll(mine_cnt));
+        const unsigned olo = (unsigned)__builtin_amdgcn_ds_bpermute(cls * 4, (int)(unsigned)off);
+        const unsigned ohi = (unsigned)__builtin_amdgcn_ds_bpermute(cls * 4, (int)(unsigned)(off >> 32));
+        if (has) {
+            const unsigned long long mb_ = cls == 0 ? bc[0] : (cls == 1 ? bc[1] : (cls == 2 ? bc[2] : bc[3]));
+            const unsigned long long slot = (((unsigned long long)ohi << 32) | olo) +
+                                            __builtin_amdgcn_mbcnt_hi((unsigned)(mb_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb_, 0u));
+            const unsigned sub = (unsigned)(m.cls_base[cls] + (int)(blockIdx.x % (unsigned)m.cls_groups[cls]));
+            const unsigned long long b = (unsigned long long)(base_cfg + (it & 63u));
+            if (slot < cap_sub) q_items[(unsigned long long)sub * cap_sub + slot] = (b << 20) | (unsigned long long)(it >> 6);
+        }
     }
     __syncthreads();
 }
@@ -1113,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
 // back with wave-uniform addresses (broadcast reads), so the pair loop touches no scalar or vector memory
 // and is a straight line per category.  Survivors are collected as one bit per (lane, pair) and turned into
 // queue items 64 pairs at a time.
-NBK_DEV void enqueue_bits(unsigned long long bits, int jbase, const double* lds_pc, unsigned* lds_queue, int& qn, int lane,
+NBK_DEV void enqueue_bits(const DevModel& m, unsigned long long bits, int jbase, const double* lds_pc, unsigned* lds_queue, int& qn, int lane,
                           int64_t base, unsigned long long* q_count, unsigned long long* q_items, unsigned long long cap) {
     while (true) {
         const bool has = bits != 0ull;
@@ -1128,7 +1147,7 @@ NBK_DEV void enqueue_bits(unsigned long long bits, int jbase, const double* lds_
             lds_queue[pos] = (p << 6) | (unsigned)lane;
         }
         qn += __builtin_popcountll(bal);
-        if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+        if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
     }
 }
 
@@ -1306,11 +1325,11 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
                 }
             }
             if (!active || hit || (m.dbg & 4)) bits = 0ull;
-            enqueue_bits(bits, j0 + c0, lds_pc, lds_queue, qn, lane, base, q_count, q_items, cap);
+            enqueue_bits(m, bits, j0 + c0, lds_pc, lds_queue, qn, lane, base, q_count, q_items, cap);
         }
         j0 += ncat;
     }
-    if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
+    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane);
     // the mask starts from the hits certified here; k_narrow ORs the rest in
     const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
@@ -1469,7 +1488,7 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
                     lds_queue[pos] = (p << 6) | (unsigned)lane;
                 }
                 qn += __builtin_popcountll(bal);
-                if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
             }
         }
     }
@@ -1531,10 +1550,10 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
                 lds_queue[pos] = (p << 6) | (unsigned)lane;
             }
             qn += __builtin_popcountll(bal);
-            if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
         }
     }
-    if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
+    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane);
     const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
@@ -1717,7 +1736,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                     lds_queue[pos] = (p << 6) | (unsigned)lane;
                 }
                 qn += __builtin_popcountll(bal);
-                if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
             }
         }
     }
@@ -1796,10 +1815,10 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 lds_queue[pos] = (p << 6) | (unsigned)lane;
             }
             qn += __builtin_popcountll(bal);
-            if (qn > BQ_CAP - WAVE) { flush_items(lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
         }
     }
-    if (qn > 0) flush_items(lds_queue, qn, base, q_count, q_items, cap, lane);
+    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane);
     const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
@@ -2016,7 +2035,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
 
 // experiment (NBK_SORT_ITEMS): sorts every sub-queue by (pair, configuration) so that the chunks k_narrow takes are
 // pair-homogeneous; one workgroup per sub-queue, up to 4096 items in LDS, bitonic
-__global__ __launch_bounds__(256) void k_sort_items(unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
+__global__ __launch_bounds__(256) void k_sort_items(DevModel m, int mode, unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
                                                      unsigned long long cap) {
     __shared__ unsigned long long key[4096];
     const unsigned sub = blockIdx.x;
@@ -2026,7 +2045,22 @@ __global__ __launch_bounds__(256) void k_sort_items(unsigned long long* __restri
     unsigned long long* it = q_items + (unsigned long long)sub * cap;
     for (int i = threadIdx.x; i < 4096; i += 256) {
         unsigned long long v = ~0ull;
-        if ((unsigned long long)i < n) { const unsigned long long x = it[i]; v = ((x & 0xFFFFFull) << 44) | (x >> 20); }
+        if ((unsigned long long)i < n) {
+            const unsigned long long x = it[i];
+            const unsigned long long p = x & 0xFFFFFull, cfg = x >> 20;
+            if (mode == 1) v = (p << 44) | cfg;                       // pair-major
+            else {
+                // coarse classes, pairs mixed inside a class: 2 = joints to replay (depth of the deeper shape, in twos),
+                // 3 = kind pair, 4 = both
+                const int4 info = m.vp_info[(int)p];
+                const unsigned mk = (unsigned)info.z | (unsigned)info.w;
+                const unsigned depth = mk ? 32u - (unsigned)__builtin_clz(mk) : 0u;
+                const unsigned ka = info.x >= 0 ? (unsigned)m.rs_kind[info.x] : (unsigned)m.ws_kind[~info.x];
+                const unsigned kb = info.y >= 0 ? (unsigned)m.rs_kind[info.y] : (unsigned)m.ws_kind[~info.y];
+                const unsigned long long cls = mode == 2 ? (depth / 2) : (mode == 3 ? (ka * 8 + kb) : ((depth / 2) * 64 + ka * 8 + kb));
+                v = (cls << 54) | ((cfg & 0x3FFFFFFFFull) << 20) | p;
+            }
+        }
         key[i] = v;
     }
     __syncthreads();
@@ -2042,7 +2076,10 @@ __global__ __launch_bounds__(256) void k_sort_items(unsigned long long* __restri
             }
             __syncthreads();
         }
-    for (int i = threadIdx.x; (unsigned long long)i < n; i += 256) { const unsigned long long v = key[i]; it[i] = ((v & 0xFFFFFFFFFFFull) << 20) | (v >> 44); }
+    for (int i = threadIdx.x; (unsigned long long)i < n; i += 256) {
+        const unsigned long long v = key[i];
+        it[i] = mode == 1 ? (((v & 0xFFFFFFFFFFFull) << 20) | (v >> 44)) : ((((v >> 20) & 0x3FFFFFFFFull) << 20) | (v & 0xFFFFFull));
+    }
 }
 
 __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
@@ -2732,7 +2769,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     Blob B;
     nbk_model* M = new nbk_model();
     memset(&M->d, 0, sizeof(M->d));
-    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi, ft, bs; } o;
+    struct Off { size_t jt, jq, jl, js, jb, jr, jtr, jsl, jax, bp, rk, rr, rl, rc, wk, wc, pa, pb, pu, vt, vc, vk, wz, rm, bt, rf, vi, ft, bs, vcl; } o;
     o.jt = B.add(d->joint_type, sizeof(int) * J);
     o.jq = B.add(d->joint_qidx, sizeof(int) * J);
     o.jl = B.add(load.data(), sizeof(int) * J);
@@ -2765,6 +2802,29 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         vp_info[4 * i + 3] = rb >= 0 ? (int)rs_mask[rb] : 0;
     }
     o.vi = B.add(vp_info.data(), sizeof(int) * 4 * P);
+    std::vector<int> vp_cls((size_t)(P > 0 ? P : 1), 3);
+    int cls_count[4] = {0, 0, 0, 0};
+    for (int i = 0; i < P; ++i) {
+        const int ra = vp_canon[2 * i], rb = vp_canon[2 * i + 1];
+        const int ka = ra >= 0 ? rs_kind[ra] : ws_kind[~ra], kb = rb >= 0 ? rs_kind[rb] : ws_kind[~rb];
+        vp_cls[i] = (ka == K_BOX && kb == K_BOX) ? 0 : ((ka == K_BOX && kb == K_CYL) ? 1 : ((ka == K_CYL && kb == K_CYL) ? 2 : 3));
+        cls_count[vp_cls[i]] += 1;
+    }
+    // sub-queues per class in proportion to its pairs (at least one for a class that has pairs)
+    int cls_groups[4] = {0, 0, 0, 0}, cls_base[4] = {0, 0, 0, 0};
+    {
+        int used = 0, nonempty = 0;
+        for (int c = 0; c < 4; ++c) if (cls_count[c] > 0) ++nonempty;
+        const int spare = NSUB - nonempty;
+        for (int c = 0; c < 4; ++c)
+            if (cls_count[c] > 0) { cls_groups[c] = 1 + (int)((long long)spare * cls_count[c] / (P > 0 ? P : 1)); used += cls_groups[c]; }
+        // hand what rounding left over to the largest class
+        int big = 0;
+        for (int c = 1; c < 4; ++c) if (cls_count[c] > cls_count[big]) big = c;
+        if (P > 0) cls_groups[big] += NSUB - used;
+        for (int c = 1; c < 4; ++c) cls_base[c] = cls_base[c - 1] + cls_groups[c - 1];
+    }
+    o.vcl = B.add(vp_cls.data(), sizeof(int) * P);
     // float32 tables + error slack of the conservative broadphase.  Position error of a float32 chain sweep is below
     // (joints + 2) * 16 ulp(float) * reach; the slack is 50x that, never below 1e-4 of the reach.
     std::vector<float> ftab;
@@ -2848,6 +2908,8 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.n_plane_pairs = n_plane; m.n_closed_pairs = n_closed;
     m.rs_mask = reinterpret_cast<const unsigned*>(base + o.rm);
     m.vp_info = reinterpret_cast<const int4*>(base + o.vi);
+    m.vp_cls = reinterpret_cast<const int*>(base + o.vcl);
+    for (int c = 0; c < 4; ++c) { m.cls_base[c] = cls_base[c]; m.cls_groups[c] = cls_groups[c] > 0 ? cls_groups[c] : 1; }
     m.f_tab = reinterpret_cast<const float*>(base + o.ft);
     m.f_trans = f_trans; m.f_slide = f_slide; m.f_base = f_base; m.f_tl = f_tl; m.f_wc = f_wc;
     // relative slack: 50 x the float32 error bound (joints + 2) * 16 ulp of a chain sweep; the kernel multiplies it by the
@@ -2869,6 +2931,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     M->margins_zero = margins_zero;
+    for (int c = 0; c < 4; ++c) M->cls_count[c] = cls_count[c];
     M->gjk_margins = gjk_margins;
     M->lds_broad_ok = lds_broad_ok;
     M->parked_ok = parked_ok;
@@ -3051,11 +3114,27 @@ static inline size_t broad_lds(const nbk_model* m) {
     return sizeof(double) * (WAVE * (qrows + 12 * (size_t)m->d.frame_slots + 3 * (size_t)m->d.n_rshapes) + 4 * (size_t)m->d.n_pairs + 18 * (size_t)m->d.n_wshapes);
 }
 
+// capacity (items) of one sub-queue for a tile of nblk 64-configuration blocks: the blocks that feed it times 64 times
+// the pairs of its class, maximised over the classes (all sub-queues get the same stride)
+static inline unsigned long long sub_queue_cap(const nbk_model* m, unsigned long long nblk) {
+    unsigned long long cap = WAVE;
+    for (int c = 0; c < 4; ++c) {
+        if (m->cls_count[c] == 0) continue;
+        const unsigned long long g = (unsigned long long)m->d.cls_groups[c];
+        const unsigned long long v = ((nblk + g - 1) / g) * WAVE * (unsigned long long)m->cls_count[c];
+        if (v > cap) cap = v;
+    }
+    return cap;
+}
+
 // configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
 static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
-    const int64_t P = m->n_pairs > 0 ? m->n_pairs : 1;
+    // worst-case queue bytes per configuration: NSUB sub-queues of the stride the fullest class needs
+    double per_cfg = 1.0;
+    for (int c = 0; c < 4; ++c) if (m->cls_count[c] > 0) { const double v = (double)NSUB * m->cls_count[c] / m->d.cls_groups[c]; if (v > per_cfg) per_cfg = v; }
+    const int64_t P = (int64_t)per_cfg + 1;
     // scenes with many pairs get up to 8 GiB (of 288 GB) so that a tile still fills the chip
-    const size_t ws_max = P > 512 ? (size_t(8) << 30) : WS_MAX_BYTES;
+    const size_t ws_max = m->n_pairs > 512 ? (size_t(8) << 30) : WS_MAX_BYTES;
     int64_t t = (int64_t)((ws_max - ws_header(m)) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
     t = (t / WAVE) * WAVE;
     // never less than two blocks per sub-queue: scenes with thousands of pairs get a workspace above WS_MAX_BYTES instead
@@ -3081,7 +3160,8 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
         const unsigned nblk = blocks_for(nb);
         // worst case per sub-queue: every pair of every configuration of the blocks that map to it
-        const unsigned long long cap_sub = (unsigned long long)((nblk + NSUB - 1) / NSUB) * WAVE * (unsigned long long)m->n_pairs;
+        // a sub-queue takes one kind class of the blocks of one group (every 64th block): worst case all pairs of that class
+        const unsigned long long cap_sub = sub_queue_cap(m, nblk);
         EdgeSrc es_tile = es;
         if (es.map != nullptr) es_tile.map = es.map + b0;
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
@@ -3120,7 +3200,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
         // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
         // distance predicate only, else the build with both
-        if (getenv("NBK_SORT_ITEMS")) hipLaunchKernelGGL(k_sort_items, dim3(NSUB), dim3(256), 0, st, items, count, cap_sub);
+        if (getenv("NBK_SORT_ITEMS")) hipLaunchKernelGGL(k_sort_items, dim3(NSUB), dim3(256), 0, st, m->d, atoi(getenv("NBK_SORT_ITEMS")), items, count, cap_sub);
         bool any_zero = false, any_nonzero = false, any_negative = false;
         for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
             const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
@@ -3142,7 +3222,7 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
 
 static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
     const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
-    return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * ((nblk + NSUB - 1) / NSUB) * WAVE * (int64_t)(m->n_pairs > 0 ? m->n_pairs : 1);
+    return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * (int64_t)sub_queue_cap(m, (unsigned long long)nblk);
 }
 
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
