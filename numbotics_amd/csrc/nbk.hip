@@ -109,6 +109,12 @@ struct nbk_model {
     // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
     void* ws;
     size_t ws_bytes;
+    // the internal workspace keeps its float32 broadphase tables between calls with the same threshold, and two sets of queue
+    // counters: a call uses set (epoch & 1) and its narrowphase clears the other one for the next call -- no prepare launch
+    bool ws_ready;
+    double ws_thr;
+    unsigned ws_epoch;
+    hipStream_t ws_stream;    // stream of the last call that used the internal workspace: a call on another stream first waits for it
     void* ews;                // scratch of the batched edge path
     size_t ews_bytes;
     std::mutex mu;
@@ -1078,10 +1084,10 @@ __global__ void k_zero_counters(unsigned long long* __restrict__ q_count) {
 //   rho [16]    float  bounding radius of robot shape a, rounded up
 NBK_DEV size_t ftab_entries(int W) { return 2 * 256 + 3 * (size_t)W * 16 + 16; }
 
-__global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, unsigned long long* __restrict__ q_count, float* __restrict__ tab) {
+__global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, unsigned long long* __restrict__ q_count, int n_sets, float* __restrict__ tab) {
     const int t = threadIdx.x;
     const int W = m.n_wshapes;
-    q_count[t * CNT_STRIDE] = 0ull;
+    for (int s = 0; s < n_sets; ++s) q_count[((size_t)s * NSUB + t) * CNT_STRIDE] = 0ull;
     float* rkey = tab;
     int* rp = reinterpret_cast<int*>(tab + 256);
     float* wkey = tab + 512;
@@ -1876,11 +1882,13 @@ template <int MODE>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
                          const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
                          unsigned long long cap, uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
-                         double* qstage) {
+                         double* qstage, unsigned long long* __restrict__ count_next) {
     // block (sub, part): every nparts-th 128-item chunk of sub-queue `sub`
     const unsigned sub = blockIdx.x % NSUB;
     const unsigned part = blockIdx.x / NSUB;
     const unsigned nparts = gridDim.x / NSUB;
+    // the other counter set is idle during this call: clear it for the next one
+    if (count_next != nullptr && part == 0 && threadIdx.x == 0) count_next[(size_t)sub * CNT_STRIDE] = 0ull;
     // agent-scope loads: the queue was written by another kernel (possibly replayed from a hipGraph).
     // The kernel is latency-bound, so dependent global round trips are kept to three: {count, first item} ->
     // {pair record, q row} -> shape constants.  The first chunk's item is loaded before the count is known (the slot
@@ -2085,33 +2093,37 @@ __global__ __launch_bounds__(256) void k_sort_items(DevModel m, int mode, unsign
 __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                       const unsigned long long* __restrict__ q_items,
                                                       const unsigned long long* __restrict__ q_count, unsigned long long cap,
-                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+    unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    narrow_body<1>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+    narrow_body<1>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage, count_next);
 }
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                  const unsigned long long* __restrict__ q_items,
                                                  const unsigned long long* __restrict__ q_count, unsigned long long cap,
-                                                 uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+                                                 uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+    unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    narrow_body<0>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+    narrow_body<0>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage, count_next);
 }
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pred(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                       const unsigned long long* __restrict__ q_items,
                                                       const unsigned long long* __restrict__ q_count, unsigned long long cap,
-                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+    unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    narrow_body<2>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+    narrow_body<2>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage, count_next);
 }
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pos(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                      const unsigned long long* __restrict__ q_items,
                                                      const unsigned long long* __restrict__ q_count, unsigned long long cap,
-                                                     uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+                                                     uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
+    unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
-    narrow_body<3>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage);
+    narrow_body<3>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage, count_next);
 }
 
 // MODE 0: min distance + argmin; MODE 1: all pair distances; MODE 2: all pair distances + witnesses;
@@ -2926,7 +2938,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     for (int i = 0; i < P; ++i) m.bq_count[bq_tab[4 * i + 3]]++;
     { const char* ab = getenv("NBK_ABLATE"); m.dbg = ab ? atoi(ab) : 0; }
     M->blob = dev;
-    M->ws = nullptr; M->ws_bytes = 0;
+    M->ws = nullptr; M->ws_bytes = 0; M->ws_ready = false; M->ws_thr = 0.0; M->ws_epoch = 0; M->ws_stream = nullptr;
     M->ews = nullptr; M->ews_bytes = 0;
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
@@ -3104,7 +3116,8 @@ static inline size_t collide_lds(const nbk_model* m) {
 // ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
 static const int64_t TWO_KERNEL_MIN_B = getenv("NBK_TWO_KERNEL_MIN_B") ? atoll(getenv("NBK_TWO_KERNEL_MIN_B")) : 8192;
 static const size_t WS_MAX_BYTES = size_t(1) << 30;
-static const size_t WS_COUNTERS = NSUB * CNT_STRIDE * 8;      // NSUB counters, one cache line each
+static const size_t WS_COUNTER_SET = NSUB * CNT_STRIDE * 8;    // NSUB counters, one cache line each
+static const size_t WS_COUNTERS = 2 * WS_COUNTER_SET;          // two sets (see nbk_model::ws_epoch)
 static inline size_t ws_header(const nbk_model* m) {           // counters | per-call float32 broadphase tables
     return (WS_COUNTERS + 4 * (2 * 256 + 3 * (size_t)m->d.n_wshapes * 16 + 16) + 255) & ~size_t(255);
 }
@@ -3151,9 +3164,32 @@ static inline size_t broad_reg_lds(const nbk_model* m, int S) {
 
 // broadphase + narrowphase over B configurations (plain q rows, or the samples described by `es`), tiled so
 // that the worst-case queue fits the workspace
+static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+                                      uint8_t* mask_bytes, void* workspace, hipStream_t st, bool internal);
+
+// the internal workspace is one per descriptor: work queued on another stream must have drained before this stream reuses it
+static int32_t internal_ws_enter(nbk_model* mm, hipStream_t st) {
+    if (mm->ws != nullptr && mm->ws_stream != st) {
+        NBK_HIP(hipStreamSynchronize(mm->ws_stream));
+        mm->ws_ready = false;
+    }
+    mm->ws_stream = st;
+    return NBK_OK;
+}
+
+// `internal`: the workspace is the descriptor's own (caller holds its mutex) and keeps state between calls
 static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
-                                 uint8_t* mask_bytes, void* workspace, hipStream_t st) {
-    unsigned long long* count = static_cast<unsigned long long*>(workspace);
+                                 uint8_t* mask_bytes, void* workspace, hipStream_t st, bool internal = false) {
+    const int32_t rc = launch_two_kernel_impl(m, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, internal);
+    if (rc != NBK_OK && internal) const_cast<nbk_model*>(m)->ws_ready = false;      // whatever state the queues are in: start over
+    return rc;
+}
+
+static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+                                      uint8_t* mask_bytes, void* workspace, hipStream_t st, bool internal) {
+    nbk_model* mm = const_cast<nbk_model*>(m);
+    unsigned long long* count_set0 = static_cast<unsigned long long*>(workspace);
+    unsigned long long* count = count_set0;
     unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_header(m));
     const int64_t tile = tile_configs(m, B);
     for (int64_t b0 = 0; b0 < B; b0 += tile) {
@@ -3175,10 +3211,23 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
         const size_t qrows_f = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
         const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16;
-        if (use_reg && f32)
-            hipLaunchKernelGGL(k_prepare_f32, dim3(1), dim3(NSUB), 0, st, m->d, threshold, count, ftab);      // clears the counters too
-        else
+        unsigned long long* count_next = nullptr;
+        if (use_reg && f32) {
+            if (internal && mm->ws_ready && mm->ws_thr == threshold) {
+                // tables are in place and the previous call's narrowphase cleared this call's counter set: no launch
+                count = count_set0 + (size_t)(mm->ws_epoch & 1u) * NSUB * CNT_STRIDE;
+                count_next = count_set0 + (size_t)((mm->ws_epoch + 1u) & 1u) * NSUB * CNT_STRIDE;
+            } else {
+                count = count_set0;
+                hipLaunchKernelGGL(k_prepare_f32, dim3(1), dim3(NSUB), 0, st, m->d, threshold, count_set0, internal ? 2 : 1, ftab);   // clears the counters too
+                if (internal) { mm->ws_ready = true; mm->ws_thr = threshold; mm->ws_epoch = 0; count_next = count_set0 + (size_t)NSUB * CNT_STRIDE; }
+            }
+            if (internal) mm->ws_epoch += 1u;
+        } else {
+            count = count_set0;
+            if (internal) mm->ws_ready = false;
             hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count);
+        }
         if (use_reg && f32 && S <= 8)
             hipLaunchKernelGGL(k_broad_f32<8>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
         else if (use_reg && f32 && S <= 12)
@@ -3208,13 +3257,13 @@ static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q
             if (!(tc > 0.0)) any_negative = true;          // (a NaN threshold counts as not positive)
         }
         if (!any_nonzero)
-            hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+            hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero && !any_negative)
-            hipLaunchKernelGGL(k_narrow_pos, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+            hipLaunchKernelGGL(k_narrow_pos, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero)
-            hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+            hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else
-            hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my);
+            hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         NBK_HIP(hipGetLastError());
     }
     return NBK_OK;
@@ -3245,7 +3294,8 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
         NBK_HIP(hipGetLastError());
         return NBK_OK;
     }
-    return launch_two_kernel(m, EdgeSrc{nullptr, nullptr, nullptr, nullptr}, q, B, threshold, mask_bits, mask_bytes, workspace, st);
+    return launch_two_kernel(m, EdgeSrc{nullptr, nullptr, nullptr, nullptr}, q, B, threshold, mask_bits, mask_bytes, workspace, st,
+                             workspace == m->ws);      // the descriptor's own workspace: nbk_validity_batch holds its mutex
 }
 
 int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
@@ -3255,8 +3305,10 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
     if (need <= 0) return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, nullptr, 0, stream);
     nbk_model* mm = const_cast<nbk_model*>(m);
     std::lock_guard<std::mutex> lock(mm->mu);          // one internal workspace: calls on one model serialise here
+    { const int32_t e_ = internal_ws_enter(mm, (hipStream_t)stream); if (e_ != NBK_OK) return e_; }
     if (mm->ws_bytes < (size_t)need) {
         if (mm->ws) { NBK_HIP(hipStreamSynchronize((hipStream_t)stream)); NBK_HIP(hipDeviceSynchronize()); (void)hipFree(mm->ws); mm->ws = nullptr; mm->ws_bytes = 0; }
+        mm->ws_ready = false;
         hipError_t e = hipMalloc(&mm->ws, (size_t)need);
         if (e != hipSuccess) { hip_fail(e, "hipMalloc(workspace)"); return NBK_ERR_ALLOC; }
         mm->ws_bytes = (size_t)need;
@@ -3367,12 +3419,14 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
     }
     unsigned long long* map = reinterpret_cast<unsigned long long*>(static_cast<char*>(mm->ews) + head);
     uint64_t* words = reinterpret_cast<uint64_t*>(static_cast<char*>(mm->ews) + head + map_bytes);
+    { const int32_t e_ = internal_ws_enter(mm, st); if (e_ != NBK_OK) return e_; }
+    if (mm->ws_bytes < (size_t)two_kernel_workspace_bytes(m, (int64_t)total)) mm->ws_ready = false;     // about to be reallocated
     rc = grow(mm->ws, mm->ws_bytes, (size_t)two_kernel_workspace_bytes(m, (int64_t)total));
     if (rc != NBK_OK) return rc;
     hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, map);
     NBK_HIP(hipGetLastError());
     EdgeSrc es{starts, goals, plan, map};
-    rc = launch_two_kernel(m, es, nullptr, (int64_t)total, threshold, words, nullptr, mm->ws, st);
+    rc = launch_two_kernel(m, es, nullptr, (int64_t)total, threshold, words, nullptr, mm->ws, st, true);
     if (rc != NBK_OK) return rc;
     hipLaunchKernelGGL(k_edge_reduce, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, words, valid);
     NBK_HIP(hipGetLastError());

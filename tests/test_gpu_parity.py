@@ -888,6 +888,32 @@ def test_misaligned_views_and_extreme_thresholds(fresh_world, torch_cuda):
         assert want.all() if thr > 0 else not want.any()
 
 
+def test_internal_workspace_state_across_thresholds_streams_and_sizes(fresh_world, torch_cuda):
+    """nbk_validity_batch keeps its broadphase tables and alternates two counter sets between calls; changing the threshold,
+    the batch size (tiles / reallocation), the stream, or interleaving edge batches must not leak state."""
+    torch = torch_cuda
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    q = sample_q(chain, 60000, seed=97)
+    qt = torch.from_numpy(q).cuda()
+    ref = {thr: orc.validity(q, thr, nthreads=8) for thr in (0.0, 1e-6, 0.02)}
+    side = torch.cuda.Stream()
+    seq = [(0.0, 20000), (0.0, 20000), (0.0, 60000), (1e-6, 9000), (1e-6, 9000), (0.0, 9000), (0.02, 33333), (0.0, 60000), (0.0, 8192)]
+    for k, (thr, n) in enumerate(seq):
+        if k % 3 == 2:
+            with torch.cuda.stream(side):
+                got = dev.validity(qt[:n], thr)
+            side.synchronize()
+        else:
+            got = dev.validity(qt[:n], thr)
+        assert np.array_equal(got.cpu().numpy(), ref[thr][:n]), (k, thr, n)
+        if k == 4:                                   # an edge batch shares the workspace
+            ok, _, _ = dev.edge_validity(q[:300], q[300:600], 0.05, 1.5)
+            okr, _, _ = orc.edge_validity(q[:300], q[300:600], 0.05, 1.5)
+            assert np.array_equal(ok, okr)
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
