@@ -914,6 +914,35 @@ def test_internal_workspace_state_across_thresholds_streams_and_sizes(fresh_worl
             assert np.array_equal(ok, okr)
 
 
+def test_descriptor_lifecycle_does_not_leak(fresh_world, torch_cuda):
+    """Descriptors own device memory (tables, the validity workspace, edge scratch, frame sets): building, using and
+    dropping 60 of them returns it."""
+    import gc
+    torch = torch_cuda
+    from numbotics_amd.engine import DeviceModel
+    arm, chain, obs = build_scene("c2")
+    sm = arm.scene_model()
+    q = torch.from_numpy(sample_q(chain, 20000, seed=99)).cuda()
+    names = list(sm.kin.frames.keys())[:4]
+
+    def cycle():
+        dev = DeviceModel(sm)
+        dev.validity(q, 0.0)
+        dev.edge_validity(q[:64], q[64:128], 0.05, 1.0)
+        dev.fk_frames(q[:256], names)
+        del dev
+
+    for _ in range(3):
+        cycle()
+    gc.collect(); torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(60):
+        cycle()
+    gc.collect(); torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 * 1024 * 1024, (free0, free1)         # the workspace alone is 40 MB per descriptor
+
+
 def test_capi_argument_errors_and_graph_capture(fresh_world, torch_cuda):
     """Status codes instead of exceptions across the C boundary; the workspace variant of the validity call is
     capturable into a HIP graph (no allocation, no synchronisation) and replays bit-identically."""
