@@ -204,6 +204,24 @@ def test_shape_zoo_distances(fresh_world, torch_cuda):
         assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])      # fused kernel
 
 
+def test_one_wave_per_edge_kernel_still_agrees(fresh_world, torch_cuda):
+    """k_edges (one wave per edge) is no longer the default for small edge counts; NBK_EDGE_BATCH_MIN_E brings it back."""
+    import os
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    q = sample_q(chain, 60, seed=44)
+    os.environ["NBK_EDGE_BATCH_MIN_E"] = "1000"
+    try:
+        for mode in ("connect", "steer"):
+            ok, end, ns = dev.edge_validity(q[:30], q[30:], 0.02, 1.0, mode=mode)
+            okr, endr, nsr = orc.edge_validity(q[:30], q[30:], 0.02, 1.0, mode=mode)
+            assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
+            assert_bitwise(end, endr, "k_edges end states")
+    finally:
+        del os.environ["NBK_EDGE_BATCH_MIN_E"]
+
+
 @pytest.mark.parametrize("mode", ["connect", "steer"])
 def test_edge_validity(fresh_world, mode, torch_cuda):
     from numbotics_amd.planning.sampling_based import ConnectorParams, DiscreteConnector
