@@ -150,7 +150,8 @@ int32_t nbk_validity_batch(const nbk_model *m, const double *q, int64_t B, doubl
 /*
  * Same, with caller-owned scratch.  Large batches run as a broadphase kernel that appends the surviving
  * (configuration, pair) items to a queue in `workspace`, followed by a dense narrowphase kernel.
- * nbk_validity_workspace_bytes(m, B) gives the size needed (0 = the fused single-kernel path is used).  The queue is sized
+ * nbk_validity_workspace_bytes(m, B) gives the size needed (0 only for B = 0 or a descriptor without pairs; a call that passes
+ * no workspace runs the slower fused single-kernel path).  The queue is sized
  * for the worst case (every pair of every configuration of a tile survives): up to 1 GiB, up to 8 GiB for descriptors with
  * more than 512 pairs; larger batches are processed in tiles of that size.
  * nbk_validity_batch itself keeps one internal workspace per descriptor (grown with hipMalloc on demand,

@@ -20,6 +20,19 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
 
 
+class fused_path:
+    """Route small batches through the fused kernel k_validity (the default sends every size through broadphase + narrowphase)."""
+
+    def __enter__(self):
+        import os
+        os.environ["NBK_TWO_KERNEL_MIN_B"] = "1000000000"
+
+    def __exit__(self, *exc):
+        import os
+        del os.environ["NBK_TWO_KERNEL_MIN_B"]
+        return False
+
+
 def assert_bitwise(a, b, what):
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape, (what, a.shape, b.shape)
@@ -119,20 +132,27 @@ def test_validity_mask_bitwise(fresh_world, scene, torch_cuda):
 
 
 def test_fused_and_two_kernel_paths_agree(fresh_world, torch_cuda):
-    """Small batches run the fused kernel, large ones broadphase + compacted narrowphase; same predicate, same
-    bits -- also with a caller-owned workspace and for every shape class of the zoo scene."""
+    """The fused kernel (NBK_TWO_KERNEL_MIN_B raises the hand-over size; it is also what a nbk_validity_batch_ws call without
+    a workspace runs) and broadphase + narrowphase: same predicate, same bits -- also with a caller-owned workspace."""
+    import os
     torch = torch_cuda
     arm, chain, obs = build_scene("c3")
     _, dev = arm._scene_device()
     orc = Oracle(arm.scene_model())
     q = sample_q(chain, 40000, seed=12)
     for thr in (0.0, 0.01, -0.002):
-        big = dev.validity(q, thr)                                        # two-kernel path (B >= 8192)
-        small = np.concatenate([dev.validity(q[i:i + 4096], thr) for i in range(0, 40000, 4096)])   # fused path
-        assert np.array_equal(big, small)
+        big = dev.validity(q, thr)                                        # broadphase + narrowphase
+        small = np.concatenate([dev.validity(q[i:i + 4096], thr) for i in range(0, 40000, 4096)])
+        os.environ["NBK_TWO_KERNEL_MIN_B"] = "1000000"
+        try:
+            assert dev.validity_workspace_bytes(4096) == 0
+            fused = np.concatenate([dev.validity(q[i:i + 4096], thr) for i in range(0, 40000, 4096)])   # fused kernel
+        finally:
+            del os.environ["NBK_TWO_KERNEL_MIN_B"]
+        assert np.array_equal(big, small) and np.array_equal(big, fused)
         assert np.array_equal(big, orc.validity(q, thr, nthreads=8))
     need = dev.validity_workspace_bytes(40000)
-    assert need > 0 and dev.validity_workspace_bytes(100) == 0
+    assert need > 0 and dev.validity_workspace_bytes(100) > 0 and dev.validity_workspace_bytes(0) == 0
     ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
     assert np.array_equal(dev.validity(q, 0.0, workspace=ws), big if thr == 0.0 else dev.validity(q, 0.0))
     words = dev.validity(q, 0.0, packed=True, workspace=ws)
@@ -201,7 +221,8 @@ def test_shape_zoo_distances(fresh_world, torch_cuda):
     for thr in (0.0, 0.03, -0.004):
         ref = orc.validity(q, thr, nthreads=8)
         assert np.array_equal(arm.in_collision(q, thr), ref)                    # broadphase + narrowphase kernels
-        assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])      # fused kernel
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])      # fused kernel
 
 
 def test_one_wave_per_edge_kernel_still_agrees(fresh_world, torch_cuda):
@@ -336,7 +357,8 @@ def test_tree_robot_with_prismatic_joints(fresh_world, torch_cuda):
     for thr in (0.0, 0.01):
         ref = orc.validity(q, thr, nthreads=8)
         assert np.array_equal(arm.in_collision(q, thr), ref)                        # register broadphase
-        assert np.array_equal(np.concatenate([arm.in_collision(q[i:i + 4000], thr) for i in range(0, 12000, 4000)]), ref)  # fused
+        with fused_path():
+            assert np.array_equal(np.concatenate([arm.in_collision(q[i:i + 4000], thr) for i in range(0, 12000, 4000)]), ref)  # fused
         os.environ["NBK_NO_REG_BROAD"] = "1"
         try:
             assert np.array_equal(arm.in_collision(q, thr), ref)                    # LDS broadphase
@@ -604,7 +626,8 @@ def test_random_mechanisms_and_scenes(fresh_world, seed, torch_cuda, tmp_path):
     for thr in (0.0, float(rng.choice([0.02, -0.003]))):
         ref = orc.validity(q, thr, nthreads=8)
         assert np.array_equal(arm.in_collision(q, thr), ref), f"two-kernel path, thr {thr}"
-        assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), f"fused path, thr {thr}"
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), f"fused path, thr {thr}"
         os.environ["NBK_NO_REG_BROAD"] = "1"
         try:
             assert np.array_equal(arm.in_collision(q, thr), ref), f"LDS broadphase, thr {thr}"
@@ -670,7 +693,8 @@ def test_contact_transitions_are_resolved_exactly(fresh_world, scene, torch_cuda
     ref = orc.validity(q, 0.0, nthreads=8)
     assert 0.2 < ref.mean() < 0.8
     assert np.array_equal(arm.in_collision(q, 0.0), ref)
-    assert np.array_equal(arm.in_collision(q[:4000], 0.0), ref[:4000])          # fused path
+    with fused_path():
+        assert np.array_equal(arm.in_collision(q[:4000], 0.0), ref[:4000])          # fused path
     for thr in (1e-7, -1e-7):
         assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr, nthreads=8))
 
@@ -809,7 +833,8 @@ def test_non_finite_joint_values_count_as_colliding(fresh_world, torch_cuda):
     ref = orc.validity(q, 0.0, nthreads=8)
     assert ref[bad_rows].all()
     assert np.array_equal(arm.in_collision(q, 0.0), ref)                       # float32 broadphase
-    assert np.array_equal(arm.in_collision(q[:3000], 0.0), ref[:3000])         # fused kernel
+    with fused_path():
+        assert np.array_equal(arm.in_collision(q[:3000], 0.0), ref[:3000])         # fused kernel
     for flag in ("NBK_F64_BROAD", "NBK_NO_REG_BROAD"):                         # float64 register / LDS broadphase
         os.environ[flag] = "1"
         try:
@@ -842,7 +867,8 @@ def test_scene_with_hundreds_of_obstacles(fresh_world, torch_cuda):
     for thr in (0.0, 0.02):
         ref = orc.validity(q, thr, nthreads=8)
         assert np.array_equal(arm.in_collision(q, thr), ref)
-        assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])          # fused kernel
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])          # fused kernel
     assert 0.05 < orc.validity(q, 0.0, nthreads=8).mean() < 0.95
     dmin, idx = arm.closest_distance(q[:300])
     dref, iref = orc.closest(q[:300])

@@ -16,4 +16,4 @@ for B in (64, 256, 1024, 2048, 4096, 8191, 8192, 16384, 65536, 131072):
     for _ in range(20): dev.validity(q, 0.0, packed=True)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)/20
-    print('B %6d  %.4f ms  %.3e configs/s  (min_B=%s)' % (B, ms, B/ms*1e3, os.environ.get('NBK_TWO_KERNEL_MIN_B','8192')))
+    print('B %6d  %.4f ms  %.3e configs/s  (min_B=%s)' % (B, ms, B/ms*1e3, os.environ.get('NBK_TWO_KERNEL_MIN_B','1')))
