@@ -431,7 +431,19 @@ class Arm(Robot):
                 and self._has(self.self_collision_pairs(), p.subject, p.target)]
 
     def closest_to(self, q):
-        return min([p for p in self.collisions(q)], key=lambda x: x.distance)
+        """``min(collisions(q), key=distance)`` (arm.py:599-600) without building the other Proximity records."""
+        if tuple(q.shape) != (self.dof,):
+            raise ValueError(f"q must be a 1D array with {self.dof} elements")
+        sm, dev = self._scene_device()
+        if sm.n_pairs == 0:
+            raise ValueError("min() arg is an empty sequence")
+        qn = q.detach().cpu().numpy() if _is_tensor(q) else np.asarray(q, dtype=np.float64)
+        dist, wit = dev.pair_distances(qn.reshape(1, -1), witness=True)
+        p = int(np.argmin(dist[0]))                       # first minimum, as min() over the list
+        subj, targ = sm.pair_members(p)
+        return Proximity(subject=subj, target=targ, position_on_subject=wit[0, p, 0:3].copy(),
+                         position_on_target=wit[0, p, 3:6].copy(), normal_target_to_subject=wit[0, p, 6:9].copy(),
+                         distance=float(dist[0, p]))
 
     def in_collision(self, q, threshold: float = 0.0):
         """``(dof,)`` -> bool as upstream (arm.py:603-604); ``(..., dof)`` -> bool array/tensor (additive)."""
