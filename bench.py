@@ -81,15 +81,24 @@ def main():
     pending = [None, None]
     counter = [0]
 
+    state = {"overlap": overlap}
+
     def gather(words):
-        if not overlap:
+        if not state["overlap"]:
             allgather_mask_words(words, gathered)
             return
         i = counter[0] & 1
         counter[0] += 1
         if pending[i] is not None:
             pending[i].wait()
-        pending[i] = dist.all_gather_into_tensor(bufs[i], words.contiguous(), async_op=True)
+        try:
+            pending[i] = dist.all_gather_into_tensor(bufs[i], words.contiguous(), async_op=True)
+        except (TypeError, RuntimeError, NotImplementedError) as exc:      # an API-level refusal is the same on every rank
+            if counter[0] != 1:
+                raise
+            state["overlap"] = False
+            print(f"[bench] overlapped gather unavailable ({exc}); using the serial form", file=sys.stderr)
+            allgather_mask_words(words, gathered)
 
     def drain():
         for i in (0, 1):
@@ -243,7 +252,7 @@ def main():
                                f"{B} q per GPU per step, threshold 0, packed bit mask"
                                + (", RCCL all-gather of mask words" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
-                   "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if overlap else "serial")),
+                   "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if state["overlap"] else "serial")),
                    "arithmetic": "every verdict is decided in float64 (bit-exact vs the CPU oracle); the broadphase culls in float32 with a slack that only lets it cull what float64 would"},
         "roofline": roofline, "fk_roofline": fk_roofline, "fk_all_links_roofline": fk_all_roofline, "cpu_baseline": cpu,
         "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",
