@@ -148,7 +148,7 @@ int32_t nbk_ik_batch(const nbk_model *m, const double *pose, const double *q0, i
 int32_t nbk_validity_batch(const nbk_model *m, const double *q, int64_t B, double threshold,
                            uint64_t *mask_bits, uint8_t *mask_bytes, void *stream);
 /*
- * Same, with caller-owned scratch.  Large batches run as a broadphase kernel that appends the surviving
+ * Same, with caller-owned scratch.  Every batch runs as a broadphase kernel that appends the surviving
  * (configuration, pair) items to a queue in `workspace`, followed by a dense narrowphase kernel.
  * nbk_validity_workspace_bytes(m, B) gives the size needed (0 only for B = 0 or a descriptor without pairs; a call that passes
  * no workspace runs the slower fused single-kernel path).  The queue is sized
