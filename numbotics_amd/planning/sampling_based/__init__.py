@@ -1,5 +1,5 @@
-__all__ = ["Connector", "ConnectorParams", "DiscreteConnector", "StateSpace", "EuclideanSpace", "PlannerParams", "PRM", "PRMStar", "RRT",
+__all__ = ["Connector", "ConnectorParams", "DiscreteConnector", "StateSpace", "EuclideanSpace", "PlannerParams", "PRM", "PRMStar", "RRT", "RRTStar",
            "Node", "knn_prefix"]
 
 from .connectors import Connector, ConnectorParams, DiscreteConnector
-from .roadmap import StateSpace, EuclideanSpace, PlannerParams, PRM, PRMStar, RRT, Node, knn_prefix
+from .roadmap import StateSpace, EuclideanSpace, PlannerParams, PRM, PRMStar, RRT, RRTStar, Node, knn_prefix

@@ -271,7 +271,8 @@ class PRM:
         while path[-1] != 0:
             path.append(int(pred[path[-1]]))
         path.reverse()
-        name = lambda i: f"v_{i}" if i < nv else f"g_{i - nv}"      # noqa: E731
+        vid = getattr(self, "vertex_ids", None)                      # planners that drop vertices keep upstream's ids
+        name = lambda i: f"v_{i if vid is None else vid[i]}" if i < nv else f"g_{i - nv}"      # noqa: E731
         return [Node(id=name(i), state=self._nodes[i], cost=float(dist[i])) for i in path]
 
 
@@ -333,4 +334,139 @@ class RRT(PRM):
         e = np.array([(a, b if b >= 0 else nv + (-1 - b)) for a, b in edges], dtype=np.int64).reshape(-1, 2)
         self.edges, self.weights = e, np.asarray(weights, dtype=np.float64)
         self.n_candidate_edges = len(edges)
+        return self
+
+
+class RRTStar(PRM):
+    """rrt_star.py:13-87: steer towards the sample, choose the cheapest parent among the near vertices, rewire the
+    others through the new vertex.  One iteration needs up to ``k_nearest`` ``connect`` calls
+    (rrt_star.py:51-58); they go to ONE ``connect_batch`` call here (one edge per wavefront), the steer before
+    them is one more launch.  The tree (parent, edge weight, cost-to-come per vertex) lives in arrays instead of a
+    networkx DiGraph; costs follow ``PlanningGraph.update_costs_recursive`` (graph.py:190-196): parent cost + edge
+    weight, pushed down the subtree on every change.
+
+    As upstream: the loop runs all ``max_iters`` iterations (it does not stop at the first goal hit); a steered
+    state within ``goal_tolerance`` of a goal is dropped again and its best parent is linked to the goal
+    (rrt_star.py:61-70); the connection radius is ``rewire_factor * (log d / d)^(1/n)``, n = graph nodes, goals
+    included (rrt_star.py:22-25).  Vertex ids stay stable when a vertex is dropped (upstream's faiss labels become
+    positional after ``remove_points`` rebuilds the index, nearest_neighbors.py:49-64 -- evidently unintended)."""
+
+    def connection_radius(self, n_nodes):
+        dim = float(self._space.dimension)
+        return self._params.rewire_factor * (np.log(dim) / dim) ** (1 / float(n_nodes))
+
+    def _push_costs(self, v):
+        stack = [v]
+        while stack:
+            u = stack.pop()
+            for c in self._children[u]:
+                self.cost[c] = self.cost[u] + self._wpar[c]
+                stack.append(c)
+
+    def plan(self, samples=None):
+        if self._start is None:
+            raise ValueError("Must set start state before planning")
+        if len(self._goals) == 0:
+            raise ValueError("Must set goal states before planning")
+        p = self._params
+        dist = self._space.distance
+        dim = self._space.dimension
+        cap = p.max_iters + 1
+        S = np.zeros((cap, dim), dtype=np.float64)
+        S32 = np.zeros((cap, dim), dtype=np.float32)
+        alive = np.zeros((cap,), dtype=bool)
+        S[0] = self._start
+        S32[0] = S[0]
+        alive[0] = True
+        n = 1
+        self.parent = [-1]
+        self._wpar = [0.0]
+        self.cost = [0.0]
+        self._children = [[]]
+        self.goal_edges = [dict() for _ in self._goals]            # per goal: parent vertex -> edge weight
+        self.n_candidate_edges = 0
+        self.n_rewired = 0
+        it = iter(samples) if samples is not None else None
+
+        def l2_32(x):
+            d = np.zeros((n,), dtype=np.float32)
+            x32 = np.asarray(x, dtype=np.float32)
+            for c in range(dim):
+                t = S32[:n, c] - x32[c]
+                d += t * t
+            d[~alive[:n]] = np.inf
+            return d
+
+        for _ in range(p.max_iters):
+            rand_state = next(it) if it is not None else self.sample_state()
+            near = int(np.argmin(l2_32(rand_state)))
+            new_state = self._connector.steer(S[near], rand_state, distance_func=dist)
+            if new_state is None:
+                continue
+            new = n
+            S[new] = new_state
+            S32[new] = S[new]
+            alive[new] = True
+            n += 1
+            self.parent.append(-1)
+            self._wpar.append(0.0)
+            self.cost.append(np.inf)
+            self._children.append([])
+            radius = self.connection_radius(int(alive[:n].sum()) + len(self._goals))
+            d32 = l2_32(S[new])
+            order = np.argsort(d32, kind="stable")[:p.k_nearest]
+            order = order[np.isfinite(d32[order])]
+            nb = order[np.linalg.norm(S[order] - S[new], axis=1) < radius]
+
+            w = np.array([dist(S[j], S[new]) for j in nb], dtype=np.float64)
+            ok = np.zeros((nb.shape[0],), dtype=bool)
+            live = w > np.finfo(np.float32).eps
+            if live.any():
+                self.n_candidate_edges += int(live.sum())
+                ok[live] = np.asarray(self._connector.connect_batch(S[nb[live]], np.tile(S[new], (int(live.sum()), 1)), w[live]))
+            best, best_cost = near, self.cost[near] + dist(S[near], S[new])
+            for j, wj, okj in zip(nb, w, ok):
+                if okj and self.cost[j] + wj < best_cost:
+                    best, best_cost = int(j), self.cost[j] + wj
+
+            for gi, g in enumerate(self._goals):
+                if dist(S[new], g) < p.goal_tolerance:
+                    alive[new] = False
+                    self.goal_edges[gi][best] = dist(S[new], g)
+                    break
+            else:
+                self.parent[new] = best
+                self._wpar[new] = dist(S[best], S[new])
+                self._children[best].append(new)
+                self.cost[new] = self.cost[best] + self._wpar[new]
+                for j, okj in zip(nb, ok):
+                    j = int(j)
+                    if not okj:
+                        continue
+                    wj = dist(S[new], S[j])
+                    if self.cost[new] + wj < self.cost[j]:                  # graph.py:181-187
+                        if self.parent[j] < 0:
+                            raise ValueError("Nodes should have one parent, found 0")
+                        self._children[self.parent[j]].remove(j)
+                        self.parent[j], self._wpar[j] = new, wj
+                        self._children[new].append(j)
+                        self.cost[j] = self.cost[new] + wj
+                        self._push_costs(j)
+                        self.n_rewired += 1
+
+        keep = np.nonzero(alive[:n])[0]
+        self.vertex_ids = keep                                       # upstream ids ``v_<id>`` of the rows of ``states``
+        remap = -np.ones((n,), dtype=np.int64)
+        remap[keep] = np.arange(keep.shape[0])
+        self.states = S[keep]
+        nv = keep.shape[0]
+        self._nodes = np.vstack([self.states] + [np.asarray(g, dtype=np.float64)[None] for g in self._goals])
+        e = [(remap[self.parent[j]], remap[j]) for j in keep if self.parent[j] >= 0]
+        wts = [self._wpar[j] for j in keep if self.parent[j] >= 0]
+        for gi, ge in enumerate(self.goal_edges):
+            for par, wg in ge.items():
+                e.append((remap[par], nv + gi))
+                wts.append(wg)
+        self.edges = np.asarray(e, dtype=np.int64).reshape(-1, 2)
+        self.weights = np.asarray(wts, dtype=np.float64)
         return self

@@ -599,6 +599,66 @@ def test_batched_prm_on_the_device(fresh_world, torch_cuda):
             assert conn.connect(a.state, b.state) is not None or conn.connect(b.state, a.state) is not None
 
 
+def test_rrt_star_on_the_device(fresh_world, torch_cuda):
+    """SURVEY.md 8(f) rank 2, RRT*: the steer and the per-iteration batch of neighbour connects run on the device; the
+    tree (vertices, parents, costs, rewires, goal links) is the one the same planner grows over the CPU oracle's edge
+    predicate."""
+    from numbotics_amd.planning.sampling_based import (ConnectorParams, DiscreteConnector, EuclideanSpace, PlannerParams, RRTStar)
+    arm, chain, obs = build_scene("c3")
+    lim = np.asarray(chain.joint_limits, dtype=np.float64)
+    space = EuclideanSpace(lim[:, 0].copy(), lim[:, 1].copy())
+    res, maxd = 0.05, 1.0
+    conn = DiscreteConnector(ConnectorParams(resolution=res, max_distance=maxd, arm=arm))
+    orc = Oracle(arm.scene_model())
+
+    class OracleConnector:
+        def is_valid(self, s):
+            return not bool(orc.validity(np.asarray(s)[None], 0.0)[0])
+
+        def steer(self, a, b, distance_func):
+            d = distance_func(a, b)
+            if d <= np.finfo(np.float32).eps:
+                return None
+            ok, end, _ = orc.edge_validity(a[None], b[None], res, maxd, mode="steer", dist=np.array([d]))
+            return np.copy(end[0]) if bool(ok[0]) else None
+
+        def connect_batch(self, A, B, dist=None):
+            return orc.edge_validity(A, B, res, maxd, mode="connect", dist=dist)[0]
+
+    rng = np.random.default_rng(21)
+    Q = sample_q(chain, 3000, seed=9)
+    free = Q[~np.asarray(arm.in_collision(Q, 0.0))]
+    start = free[0]
+    # a goal several steers away whose straight edge from the start is free: goal-biased samples then walk to it and the
+    # last steer lands on it exactly (distance 0 < goal_tolerance: the vertex is dropped, its best parent linked to the goal)
+    far = np.linalg.norm(free[1:400] - start, axis=1)
+    clear = np.asarray(conn.connect_batch(np.tile(start, (399, 1)), free[1:400], far))
+    gi = 1 + int(np.nonzero(clear & (far > 2.5))[0][0])
+    goal = free[gi]
+    pool = np.delete(free, [0, gi], axis=0)
+    params = PlannerParams(max_iters=400, k_nearest=8, goal_bias=0.1, rewire_factor=5.0, goal_tolerance=1e-6)
+    samples = [goal.copy() if rng.random() < params.goal_bias else s for s in pool[:params.max_iters]]
+    trees = []
+    for c in (conn, OracleConnector()):
+        t = RRTStar(space, c, params)
+        t.add_start(start)
+        t.add_goal(goal)
+        t.plan(samples)
+        trees.append(t)
+    dev, ref = trees
+    assert dev.states.shape[0] > 50 and dev.n_candidate_edges > 300
+    assert_bitwise(dev.states, ref.states, "rrt* vertices")
+    assert dev.parent == ref.parent and dev._wpar == ref._wpar and dev.cost == ref.cost
+    assert dev.goal_edges == ref.goal_edges and dev.n_rewired == ref.n_rewired and dev.n_candidate_edges == ref.n_candidate_edges
+    assert len(dev.goal_edges[0]) >= 1 and dev.n_rewired >= 3 and len(dev.parent) > dev.states.shape[0]
+    path = dev.solution()
+    assert path is not None and path[0].id == "v_0" and path[-1].id == "g_0"
+    for j in range(1, min(40, len(dev.parent))):                      # tree edges hold under the scalar contract too
+        if dev.parent[j] >= 0:
+            assert conn.connect(dev.states[np.searchsorted(dev.vertex_ids, dev.parent[j])],
+                                dev.states[np.searchsorted(dev.vertex_ids, j)], distance_func=space.distance) is not None
+
+
 @pytest.mark.parametrize("seed", [101, 102, 104, 106, 109, 110, 120])
 def test_random_mechanisms_and_scenes(fresh_world, seed, torch_cuda, tmp_path):
     """Fuzz: random trees (3-10 links, mixed joint types, compound links) among random obstacles (all primitive kinds,

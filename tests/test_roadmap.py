@@ -183,3 +183,107 @@ def test_rrt_grows_the_reference_tree():
     assert got == ref_edges
     path = rrt.solution()
     assert path is not None and path[0].id == "v_0" and path[-1].id == "g_0" and len(path) > 5
+
+
+def rrt_star_reference_loop(space, conn, params, start, goals, samples):
+    """rrt_star.py:28-87 restated over a dict digraph: scalar connects, costs recomputed by walking to the root
+    (what ``update_costs_recursive`` asks networkx for), subtree costs pushed recursively."""
+    state = {0: start}
+    pred = {0: {}}                    # node -> {parent: weight}
+    cost = {0: 0.0}
+    goal_pred = [dict() for _ in goals]
+    next_id, calls, rewired = 1, 0, 0
+
+    def root_cost(v):
+        c, chain = 0.0, []
+        while v != 0:
+            (par, w), = pred[v].items()
+            chain.append(w)
+            v = par
+        for w in reversed(chain):
+            c = c + w
+        return c
+
+    def push(v, base=None):
+        cost[v] = root_cost(v) if base is None else base
+        for c in [c for c in pred if v in pred[c]]:
+            push(c, cost[v] + pred[c][v])
+
+    def l2(x):
+        ids = sorted(state)
+        X = np.asarray([state[i] for i in ids], dtype=np.float32)
+        return np.asarray(ids), ((X - np.asarray(x, dtype=np.float32)) ** 2).sum(axis=1)
+
+    for s in samples:
+        ids, d = l2(s)
+        near = int(ids[np.argmin(d)])
+        new_state = conn.steer(state[near], s, distance_func=space.distance)
+        if new_state is None:
+            continue
+        new = next_id
+        next_id += 1
+        state[new], pred[new], cost[new] = new_state, {}, np.inf
+        radius = params.rewire_factor * (np.log(2.0) / 2.0) ** (1 / float(len(state) + len(goals)))
+        ids, d = l2(new_state)
+        nb = [int(j) for j in ids[np.argsort(d, kind="stable")[:params.k_nearest]]
+              if np.linalg.norm(state[int(j)] - new_state) < radius]
+        best, best_cost = near, cost[near] + space.distance(state[near], new_state)
+        edges = {}
+        for j in nb:
+            calls += space.distance(state[j], new_state) > np.finfo(np.float32).eps
+            if conn.connect(state[j], new_state, distance_func=space.distance) is not None:
+                edges[j] = True
+                c = cost[j] + space.distance(state[j], new_state)
+                if c < best_cost:
+                    best, best_cost = j, c
+        for gi, g in enumerate(goals):
+            if space.distance(new_state, g) < params.goal_tolerance:
+                del state[new], pred[new], cost[new]
+                goal_pred[gi][best] = space.distance(new_state, g)
+                break
+        else:
+            pred[new] = {best: space.distance(state[best], new_state)}
+            push(new)
+            for j in nb:
+                if j in edges:
+                    w = space.distance(new_state, state[j])
+                    if cost[new] + w < cost[j]:
+                        pred[j] = {new: w}
+                        push(j)
+                        rewired += 1
+    return state, pred, cost, goal_pred, calls, rewired
+
+
+def test_rrt_star_batched_connects_build_the_reference_tree():
+    from numbotics_amd.planning.sampling_based import RRTStar
+    rng = np.random.default_rng(11)
+    space = EuclideanSpace(np.zeros(2), np.ones(2))
+    params = PlannerParams(max_iters=700, goal_bias=0.1, k_nearest=10, goal_tolerance=0.03, rewire_factor=0.25)
+    start, goal = np.array([0.05, 0.05]), np.array([0.95, 0.95])
+    samples = [goal.copy() if rng.random() < params.goal_bias else rng.uniform(0, 1, 2) for _ in range(params.max_iters)]
+    state, pred, cost, goal_pred, calls, rewired = rrt_star_reference_loop(
+        space, SteeringDiskWorld([0.5, 0.5], 0.25), params, start, [goal], samples)
+    conn = SteeringDiskWorld([0.5, 0.5], 0.25)
+    star = RRTStar(space, conn, params)
+    star.add_start(start)
+    star.add_goal(goal)
+    star.plan(samples)
+    ids = sorted(state)
+    assert star.vertex_ids.tolist() == ids and np.array_equal(star.states, np.asarray([state[i] for i in ids]))
+    for i in ids[1:]:
+        (par, w), = pred[i].items()
+        assert star.parent[i] == par and star._wpar[i] == w and star.cost[i] == cost[i]
+    assert star.goal_edges == goal_pred and len(goal_pred[0]) >= 1
+    assert star.n_candidate_edges == calls and star.n_rewired == rewired and rewired > 20
+    # every vertex's cost is the length of its branch, and the solution is the cheapest branch into the goal
+    path = star.solution()
+    assert path is not None and path[0].id == "v_0" and path[-1].id == "g_0"
+    want = min(cost[par] + w for par, w in goal_pred[0].items())
+    assert abs(path[-1].cost - want) < 1e-12
+    # rewiring shortens: the same samples without it (k_nearest=1 -> only the vertex itself is near) cost more
+    plain = RRTStar(space, SteeringDiskWorld([0.5, 0.5], 0.25), PlannerParams(
+        max_iters=700, goal_bias=0.1, k_nearest=1, goal_tolerance=0.03, rewire_factor=0.25))
+    plain.add_start(start)
+    plain.add_goal(goal)
+    plain.plan(samples)
+    assert plain.n_rewired == 0 and plain.solution()[-1].cost >= path[-1].cost
