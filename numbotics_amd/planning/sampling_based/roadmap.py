@@ -13,7 +13,7 @@ and hands ALL candidate edges to ``DiscreteConnector.connect_batch`` -- one laun
 
 Only what PRM needs is here: the state space, the planner parameters, the roadmap (arrays + a SciPy Dijkstra
 instead of networkx).  RRT/RRT* grow a tree one steer at a time and stay sequential (``steer`` already checks a
-whole edge per call).
+whole edge per call); RRT* batches the neighbour connects of each iteration (``RRTStar`` below).
 """
 from abc import ABC, abstractmethod
 from dataclasses import dataclass
