@@ -12,7 +12,7 @@ device when there is one: ``nbk_knn_prefix``),
 and hands ALL candidate edges to ``DiscreteConnector.connect_batch`` -- one launch sequence on the device.
 
 Only what PRM needs is here: the state space, the planner parameters, the roadmap (arrays + a SciPy Dijkstra
-instead of networkx).  RRT/RRT* grow a tree one steer at a time and stay sequential (``steer`` already checks a
+instead of networkx).  RRT grows a tree one steer at a time and stays sequential (``steer`` already checks a
 whole edge per call); RRT* batches the neighbour connects of each iteration (``RRTStar`` below).
 """
 from abc import ABC, abstractmethod
