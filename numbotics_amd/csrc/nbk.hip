@@ -368,8 +368,16 @@ __global__ __launch_bounds__(64) void k_jacobian(DevModel m, PathArg path, const
 // ---- geometric Jacobian, paths of at most NJ joints: one sweep, joint axes and origins kept in registers ---------------
 // k_jacobian above sweeps the path twice and stages all 6*n_q output rows in LDS (25 KB per wave on a 7-DoF arm: 1.3
 // waves per SIMD resident).  Here the world axis w_i and origin o_i of every joint stay in registers (6 NJ doubles), the
-// columns are assembled after the single sweep, and the output goes through LDS in two halves (linear rows, then
-// angular rows): half the arithmetic, 15 KB of LDS per wave.  Same formulas, same bits.
+// columns are assembled after the single sweep, and the output goes through LDS 16 configurations at a time (see the
+// output stage below): half the arithmetic, 9 KB of LDS per wave.  Same formulas, same bits.
+constexpr int JAC_ROWS = 32;
+// One-wave workgroups exchange data through LDS without s_barrier: LDS executes a wave's instructions in order, so
+// a read issued after a write sees it.  Only the compiler has to keep the order, and outstanding global stores are
+// NOT waited for (what __syncthreads would do) -- the stores of one group overlap the assembly of the next.
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 template <int NJ>
 __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, const double* __restrict__ q, int64_t B,
                                                       int mode, const double* __restrict__ pose, double* __restrict__ J_out) {
@@ -378,7 +386,6 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nq = m.n_q;
     const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
-    double* lds_o = lds + WAVE * nq;
     {
         const int total = (int)rows * nq;
         const double* src = q + base * nq;
@@ -425,48 +432,87 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
     } else if (mode == 2 && b < B) {
         pend[0] = pose[16 * b + 3]; pend[1] = pose[16 * b + 7]; pend[2] = pose[16 * b + 11];
     }
-    const int half = 3 * nq;
-    const int stride = half + 1 + ((half + 1) & 1 ? 0 : 1);   // odd row stride: conflict-free
-    double* row = lds_o + lane * stride;
+    // Columns: v_i = w_i x (p_end - o_i) replaces o_i in its registers (a prismatic joint's linear column is w_i itself).
+    unsigned covered = 0u, revolute = 0u;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+        if (i < path.len) {
+            const int k = path.idx[i];
+            covered |= 1u << m.joint_qidx[k];
+            if (m.joint_type[k] == NBK_REVOLUTE) {
+                revolute |= 1u << i;
+                double d[3], v[3];
+                sub3(pend, Ox[i], d);
+                cross3(Wx[i], d, v);
+                Ox[i][0] = v[0]; Ox[i][1] = v[1]; Ox[i][2] = v[2];
+            } else {
+                Ox[i][0] = Wx[i][0]; Ox[i][1] = Wx[i][1]; Ox[i][2] = Wx[i][2];
+            }
+        }
+    }
+    // Output: JAC_ROWS configurations at a time.  The lanes of a group put their full rows (6 n_q doubles) into LDS (the q
+    // staging area is free by now and is reused), then the whole wave streams the group's JAC_ROWS * 6 n_q contiguous doubles
+    // out with 16-byte stores: every store instruction covers whole, contiguous cache lines.
     const int ncol = 6 * nq;
+    const int stride = ncol | 1;                              // odd row stride: conflict-free
+    double* lds_o = lds;
+    double* row = lds_o + (lane & (JAC_ROWS - 1)) * stride;
     double* dst = J_out + base * ncol;
-    const int total = (int)rows * half;
+    const bool wide = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    const unsigned all_cols = nq >= 32 ? 0xffffffffu : ((1u << nq) - 1u);
+    // the streaming loop advances (row, column) of its running element by a fixed step, without divisions
+    const int per = wide ? 2 * WAVE : WAVE;
+    const int step_r = per / ncol, step_c = per - step_r * ncol;
+    wave_lds_sync();
+    for (int grp = 0; grp < WAVE / JAC_ROWS; ++grp) {
+        if (grp * JAC_ROWS >= rows) break;
+        if ((lane / JAC_ROWS) == grp) {
+            if (covered != all_cols) {
+                for (int c = 0; c < nq; ++c)
+                    if (!((covered >> c) & 1u))
+                        for (int r = 0; r < 6; ++r) row[r * nq + c] = 0.0;
+            }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        for (int c = 0; c < half; ++c) row[c] = 0.0;
-#pragma unroll
-        for (int i = 0; i < NJ; ++i) {
-            if (i < path.len) {
-                const int k = path.idx[i];
-                const int col = m.joint_qidx[k];
-                const bool rev = m.joint_type[k] == NBK_REVOLUTE;
-                if (h == 0) {
-                    if (rev) {
-                        double d[3], v[3];
-                        sub3(pend, Ox[i], d);
-                        cross3(Wx[i], d, v);
-                        row[col] = v[0]; row[nq + col] = v[1]; row[2 * nq + col] = v[2];
-                    } else {
-                        row[col] = Wx[i][0]; row[nq + col] = Wx[i][1]; row[2 * nq + col] = Wx[i][2];
-                    }
-                } else if (rev) {
-                    row[col] = Wx[i][0]; row[nq + col] = Wx[i][1]; row[2 * nq + col] = Wx[i][2];
+            for (int i = 0; i < NJ; ++i) {
+                if (i < path.len) {
+                    double* rc = row + m.joint_qidx[path.idx[i]];
+                    const bool rev = (revolute >> i) & 1u;
+                    rc[0] = Ox[i][0]; rc += nq;
+                    rc[0] = Ox[i][1]; rc += nq;
+                    rc[0] = Ox[i][2]; rc += nq;
+                    rc[0] = rev ? Wx[i][0] : 0.0; rc += nq;
+                    rc[0] = rev ? Wx[i][1] : 0.0; rc += nq;
+                    rc[0] = rev ? Wx[i][2] : 0.0;
                 }
             }
         }
-        __syncthreads();
-        {
-            int g = lane;
-            int r = g / half, c = g - r * half;
+        wave_lds_sync();
+        const int nr = (int)rows - grp * JAC_ROWS < JAC_ROWS ? (int)rows - grp * JAC_ROWS : JAC_ROWS;
+        const int total = nr * ncol;
+        double* d = dst + (size_t)grp * JAC_ROWS * ncol;
+        int g = wide ? 2 * lane : lane;
+        int r = g / ncol, c = g - r * ncol;
+        int o = r * stride + c;
+        if (wide) {
+            for (; g < total; g += 2 * WAVE) {
+                double2 v;
+                v.x = lds_o[o];
+                v.y = lds_o[o + 1];
+                *reinterpret_cast<double2*>(d + g) = v;
+                c += step_c; o += step_r * stride + step_c;
+                if (c >= ncol) { c -= ncol; o += stride - ncol; }
+            }
+        } else {
             for (; g < total; g += WAVE) {
-                dst[(size_t)r * ncol + h * half + c] = lds_o[r * stride + c];
-                c += WAVE;
-                while (c >= half) { c -= half; ++r; }
+                d[g] = lds_o[o];
+                c += step_c; o += step_r * stride + step_c;
+                if (c >= ncol) { c -= ncol; o += stride - ncol; }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 }
+
 
 // ---- FK of many frames in one sweep (all link poses of a configuration) ---------------------------------------------
 // One tree sweep with the descriptor's load/save plan; after joint k the poses of the requested frames that hang off it
@@ -3071,9 +3117,9 @@ int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const
     if (B == 0) return NBK_OK;
     static const bool two_sweep = getenv("NBK_JAC_TWO_SWEEP") != nullptr;
     if (pa.len <= 8 && !two_sweep) {
-        const int half = 3 * m->n_q;
-        const int stride = half + 1 + ((half + 1) & 1 ? 0 : 1);
-        const size_t lds = sizeof(double) * WAVE * ((size_t)m->n_q + (size_t)stride);
+        const int stride = (6 * m->n_q) | 1;
+        const size_t lds_q = (size_t)WAVE * (size_t)m->n_q, lds_rows = (size_t)JAC_ROWS * (size_t)stride;     // the rows reuse the q area
+        const size_t lds = sizeof(double) * (lds_q > lds_rows ? lds_q : lds_rows);
         hipLaunchKernelGGL(k_jacobian_reg<8>, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, mode, pose, J_out);
         NBK_HIP(hipGetLastError());
         return NBK_OK;
