@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64) void k_fk_frames(DevModel m, const double* __re
             Xf loc, E;
             xf_from12(fs_local + 12 * f, loc);
             if (k < 0) xf_mul(bpose, loc.R, loc.t, E); else xf_mul(T, loc.R, loc.t, E);
-            __syncthreads();                                   // the previous frame's rows have been read
+            wave_lds_sync();                                   // the previous frame's rows have been read (stores stay in flight)
             double* row = lds_t + lane * 17;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(64) void k_fk_frames(DevModel m, const double* __re
                 row[4 * i + 3] = E.t[i];
             }
             row[12] = 0.0; row[13] = 0.0; row[14] = 0.0; row[15] = 1.0;
-            __syncthreads();
+            wave_lds_sync();
             const int fo = fs_out[f];
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
