@@ -219,6 +219,22 @@ def main():
                        "algorithmic_bytes_per_config": 8.0 * chain.dof + 128.0 * L}
     del TA
 
+    # ---- geometric Jacobian of the tool frame (56 in + 6 x dof x 8 out per configuration) --------
+    J = arm.jacobian(q, "tool_frame")
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(10):
+        J = arm.jacobian(q, "tool_frame")
+    e1.record()
+    torch.cuda.synchronize()
+    jac_ms = e0.elapsed_time(e1) / 10
+    jac_bytes = (hi - lo) * (8.0 * chain.dof + 48.0 * chain.dof)
+    jacobian_roofline = {"bound": "hbm", "kernel": "k_jacobian_reg", "achieved": jac_bytes / (jac_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": jac_bytes / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": jac_ms,
+                         "algorithmic_bytes": jac_bytes, "jacobians_per_s": (hi - lo) / (jac_ms * 1e-3),
+                         "algorithmic_bytes_per_config": 56.0 * chain.dof}
+    del J
+
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample ---------------------
     cpu = None
     if not args.no_cpu_baseline:
@@ -254,7 +270,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
                    "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if state["overlap"] else "serial")),
                    "arithmetic": "every verdict is decided in float64 (bit-exact vs the CPU oracle); the broadphase culls in float32 with a slack that only lets it cull what float64 would"},
-        "roofline": roofline, "fk_roofline": fk_roofline, "fk_all_links_roofline": fk_all_roofline, "cpu_baseline": cpu,
+        "roofline": roofline, "fk_roofline": fk_roofline, "fk_all_links_roofline": fk_all_roofline, "jacobian_roofline": jacobian_roofline,
+        "cpu_baseline": cpu,
         "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",
         "parity_sample": int(sl.size),
     }
