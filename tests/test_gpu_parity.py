@@ -992,6 +992,39 @@ def test_misaligned_views_and_extreme_thresholds(fresh_world, torch_cuda):
         assert want.all() if thr > 0 else not want.any()
 
 
+def test_jacobian_group_tails_and_unaligned_output(kinova, torch_cuda):
+    """k_jacobian_reg stages its rows 32 configurations at a time: batch sizes around the group and wave boundaries, every
+    pose mode, and an output slab that is only 8-byte aligned (the 8-byte store path), through the C-ABI."""
+    torch = torch_cuda
+    arm, chain, _ = kinova
+    orc = Oracle(arm._kin)
+    dev = arm._kin_device()
+    rng = np.random.default_rng(77)
+    q = sample_q(chain, 200, seed=78)
+    pose = np.tile(np.eye(4)[None], (200, 1, 1))
+    pose[:, :3, 3] = rng.normal(size=(200, 3))
+    for B in (1, 2, 31, 32, 33, 63, 64, 65, 97, 129, 200):
+        for frame in ("tool_frame", "half_arm_2_link"):
+            want = orc.jacobian(q[:B], frame)
+            assert_bitwise(arm.jacobian(q[:B], frame), want, f"jac B={B} {frame}")
+        assert_bitwise(arm.jacobian(q[:B], "tool_frame", global_pose=pose[:B]),
+                       orc.jacobian(q[:B], "tool_frame", global_pose=pose[:B]), f"jac global B={B}")
+        assert_bitwise(arm.jacobian(q[:B], "tool_frame", local_pose=pose[:B]),
+                       orc.jacobian(q[:B], "tool_frame", local_pose=pose[:B]), f"jac local B={B}")
+        # unaligned output through the C-ABI
+        path, local = dev._frame_args("tool_frame", None)
+        qt = torch.from_numpy(q[:B]).cuda()
+        slab = torch.full((B * 42 + 1,), -7.0, dtype=torch.float64, device="cuda")
+        out = slab[1:]
+        assert out.data_ptr() % 16 == 8
+        st = dev._lib.nbk_jacobian_batch(dev._h, qt.data_ptr(), B, path.ctypes.data, len(path), local.ctypes.data, 0, None,
+                                         out.data_ptr(), dev._stream())
+        assert st == 0
+        torch.cuda.synchronize()
+        assert_bitwise(out.cpu().numpy().reshape(B, 6, 7), orc.jacobian(q[:B], "tool_frame"), f"jac unaligned B={B}")
+        assert float(slab[0]) == -7.0
+
+
 def test_internal_workspace_state_across_thresholds_streams_and_sizes(fresh_world, torch_cuda):
     """nbk_validity_batch keeps its broadphase tables and alternates two counter sets between calls; changing the threshold,
     the batch size (tiles / reallocation), the stream, or interleaving edge batches must not leak state."""
