@@ -101,6 +101,7 @@ struct nbk_model {
     int n_q;
     int n_joints;
     int cls_count[4];          // pairs per kind class; cls_groups (in d) sub-queues serve each
+    std::vector<int> h_joint_qidx, h_joint_type;   // host copies for make_path
     std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
@@ -185,7 +186,8 @@ NBK_DEV void joint_apply(const DevModel& m, int k, const Xf& parent, double qk, 
 }
 
 // ---- FK of one frame -----------------------------------------------------------------------------
-struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; };
+// col / revolute / covered restate joint_qidx / joint_type along the path, so that kernels find them in scalar registers
+struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; int col[NBK_MAX_JOINTS]; unsigned revolute, covered; };
 
 // LDS: the raw q slab (64*n_q doubles) and the output rows (64 * 17 doubles) share one region: every q
 // value is in a register before the first pose element is written, so 8.7 KB per wave is all it takes and
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
         if (i < path.len) {
             const int k = path.idx[i];
             Xf nxt;
-            joint_apply(m, k, T, myq[m.joint_qidx[k]], nxt);
+            joint_apply(m, k, T, myq[path.col[i]], nxt);
             T = nxt;
             const double* a = m.joint_axis + 3 * k;
 #pragma unroll
@@ -433,14 +435,11 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
         pend[0] = pose[16 * b + 3]; pend[1] = pose[16 * b + 7]; pend[2] = pose[16 * b + 11];
     }
     // Columns: v_i = w_i x (p_end - o_i) replaces o_i in its registers (a prismatic joint's linear column is w_i itself).
-    unsigned covered = 0u, revolute = 0u;
+    const unsigned covered = path.covered, revolute = path.revolute;
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
         if (i < path.len) {
-            const int k = path.idx[i];
-            covered |= 1u << m.joint_qidx[k];
-            if (m.joint_type[k] == NBK_REVOLUTE) {
-                revolute |= 1u << i;
+            if ((revolute >> i) & 1u) {
                 double d[3], v[3];
                 sub3(pend, Ox[i], d);
                 cross3(Wx[i], d, v);
@@ -475,7 +474,7 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
                 if (i < path.len) {
-                    double* rc = row + m.joint_qidx[path.idx[i]];
+                    double* rc = row + path.col[i];
                     const bool rev = (revolute >> i) & 1u;
                     rc[0] = Ox[i][0]; rc += nq;
                     rc[0] = Ox[i][1]; rc += nq;
@@ -2988,6 +2987,8 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->ews = nullptr; M->ews_bytes = 0;
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
+    M->h_joint_qidx.assign(d->joint_qidx, d->joint_qidx + J);
+    M->h_joint_type.assign(d->joint_type, d->joint_type + J);
     M->margins_zero = margins_zero;
     for (int c = 0; c < 4; ++c) M->cls_count[c] = cls_count[c];
     M->gjk_margins = gjk_margins;
@@ -3022,7 +3023,13 @@ static int make_path(const nbk_model* m, const int32_t* path, int32_t path_len, 
         if (path[i] < 0 || path[i] >= m->n_joints) return NBK_ERR_INVALID;
         pa.idx[i] = path[i];
     }
-    for (int i = path_len; i < NBK_MAX_JOINTS; ++i) pa.idx[i] = 0;
+    pa.revolute = 0u; pa.covered = 0u;
+    for (int i = 0; i < path_len; ++i) {
+        pa.col[i] = m->h_joint_qidx[path[i]];
+        if (m->h_joint_type[path[i]] == NBK_REVOLUTE) pa.revolute |= 1u << i;
+        if (pa.col[i] >= 0 && pa.col[i] < 32) pa.covered |= 1u << pa.col[i];
+    }
+    for (int i = path_len; i < NBK_MAX_JOINTS; ++i) { pa.idx[i] = 0; pa.col[i] = 0; }
     memcpy(pa.local, local, sizeof(double) * 12);
     return NBK_OK;
 }
