@@ -667,7 +667,7 @@ NBK_DEV void ik_sweep(const DevModel& m, const PathArg& path, const double* lds_
     for (int i = 0; i < path.len; ++i) {
         const int k = path.idx[i];
         Xf nxt;
-        joint_apply(m, k, T, lds_q[m.joint_qidx[k] * WAVE + lane], nxt);
+        joint_apply(m, k, T, lds_q[path.col[i] * WAVE + lane], nxt);
         T = nxt;
         const double* a = m.joint_axis + 3 * k;
 #pragma unroll
@@ -681,10 +681,9 @@ NBK_DEV void ik_sweep(const DevModel& m, const PathArg& path, const double* lds_
     xf_mul(T, loc.R, loc.t, E);
     const int nq = m.n_q;
     for (int i = 0; i < path.len; ++i) {
-        const int k = path.idx[i];
-        const int col = m.joint_qidx[k];
+        const int col = path.col[i];
         const double w[3] = {lds_jz[(6 * i) * WAVE + lane], lds_jz[(6 * i + 1) * WAVE + lane], lds_jz[(6 * i + 2) * WAVE + lane]};
-        if (m.joint_type[k] == NBK_REVOLUTE) {
+        if ((path.revolute >> i) & 1u) {
             const double o[3] = {lds_jz[(6 * i + 3) * WAVE + lane], lds_jz[(6 * i + 4) * WAVE + lane], lds_jz[(6 * i + 5) * WAVE + lane]};
             double d[3], v[3];
             sub3(E.t, o, d);
