@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NBK_ABI_VERSION 1
+#define NBK_ABI_VERSION 2
 
 enum {
     NBK_OK = 0,
@@ -37,7 +37,7 @@ enum {
 };
 
 /* shape / joint codes used inside descriptors */
-enum { NBK_SPHERE = 0, NBK_CAPSULE = 1, NBK_BOX = 2, NBK_CYLINDER = 3, NBK_PLANE = 4 };
+enum { NBK_SPHERE = 0, NBK_CAPSULE = 1, NBK_BOX = 2, NBK_CYLINDER = 3, NBK_PLANE = 4, NBK_HULL = 5 };
 enum { NBK_REVOLUTE = 0, NBK_PRISMATIC = 1 };
 enum { NBK_CONNECT = 0, NBK_STEER = 1 };
 
@@ -63,9 +63,9 @@ typedef struct {
     const double *base_pose;      /* [12] 3x4 row-major */
     int32_t n_rshapes;            /* robot collision primitives */
     const int32_t *rshape_frame;  /* [S] moving frame carrying the shape, -1 = base */
-    const int32_t *rshape_type;   /* [S] NBK_SPHERE / CAPSULE / BOX / CYLINDER */
+    const int32_t *rshape_type;   /* [S] NBK_SPHERE / CAPSULE / BOX / CYLINDER / HULL */
     const double *rshape_local;   /* [S][12] pose of the primitive in its moving frame */
-    const double *rshape_param;   /* [S][4] sphere r | capsule r,hl | cylinder r,hl | box hx,hy,hz ; [3] = margin */
+    const double *rshape_param;   /* [S][4] sphere r | capsule r,hl | cylinder r,hl | box hx,hy,hz | hull index ; [3] = margin */
     int32_t n_wshapes;            /* static world primitives (obstacles) */
     const int32_t *wshape_type;   /* [W] the above or NBK_PLANE (param[0..2] = unit normal) */
     const double *wshape_pose;    /* [W][12] world pose */
@@ -73,6 +73,16 @@ typedef struct {
     int32_t n_pairs;              /* allowed (shape, shape) pairs, sorted by pair_a */
     const int32_t *pair_a;        /* [P] robot shape */
     const int32_t *pair_b;        /* [P] robot shape (< S) or S + world shape */
+    /* Convex hulls of MESH collision shapes (numbotics/utils/shape.py:81-94 hands the file of numbotics/utils/mesh.py:18-37
+     * to pybullet GEOM_MESH, i.e. one convex hull per mesh object; numbotics/physics/helpers.py:252-255 for URDF <mesh>).
+     * A shape of type NBK_HULL names its hull in param[0]; vertices and face planes are in the primitive's local frame,
+     * whose origin must be a point of the hull (the host uses the mean of the hull's vertices); margin inflates the hull. */
+    int32_t n_hulls;
+    const int32_t *hull_vert_begin;  /* [H+1] */
+    const double *hull_verts;        /* [NV][3] */
+    const int32_t *hull_face_begin;  /* [H+1]; a hull may have no planes (flat point set): distances stay exact, the
+                                        penetration depth then falls back to the other shape's axes and the centre line */
+    const double *hull_planes;       /* [NF][4] unit outward normal n and offset d: inside n.x <= d */
 } nbk_model_desc;
 
 typedef struct nbk_model nbk_model;

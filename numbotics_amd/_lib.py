@@ -38,6 +38,9 @@ class ModelDesc(C.Structure):
         ("wshape_type", C.c_void_p), ("wshape_pose", C.c_void_p), ("wshape_param", C.c_void_p),
         ("n_pairs", C.c_int32),
         ("pair_a", C.c_void_p), ("pair_b", C.c_void_p),
+        ("n_hulls", C.c_int32),
+        ("hull_vert_begin", C.c_void_p), ("hull_verts", C.c_void_p),
+        ("hull_face_begin", C.c_void_p), ("hull_planes", C.c_void_p),
     ]
 
 

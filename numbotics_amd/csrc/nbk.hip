@@ -137,7 +137,7 @@ static int hip_fail(hipError_t e, const char* what) {
 
 constexpr int WAVE = 64;
 
-NBK_DEV int core_rows(int kind) { return kind == K_POINT ? 3 : (kind == K_BOX ? 12 : 6); }
+NBK_DEV int core_rows(int kind) { return kind == K_POINT ? 3 : ((kind == K_BOX || kind == K_HULL) ? 12 : 6); }
 
 // ---- q staging: rows [B][n_q] -> LDS [n_q][64] ---------------------------------------------------
 // The block's slab of q is contiguous (64*n_q doubles); it is read with 16-byte loads where the slab is
@@ -873,7 +873,7 @@ NBK_DEV void sweep_and_park(const DevModel& m, double* lds_q, double* lds_s, dou
                 double u[3];
                 xf_mul_col(T, Rl, 2, u);
                 rows[3 * WAVE] = u[0]; rows[4 * WAVE] = u[1]; rows[5 * WAVE] = u[2];
-            } else if (kind == K_BOX) {
+            } else if (kind == K_BOX || kind == K_HULL) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     double u[3];
@@ -893,7 +893,7 @@ NBK_DEV void load_rcore(const DevModel& m, const double* lds_s, int s, int lane,
     o.c[0] = rows[0]; o.c[1] = rows[WAVE]; o.c[2] = rows[2 * WAVE];
     if (o.kind == K_SEG || o.kind == K_CYL) {
         o.ax[2][0] = rows[3 * WAVE]; o.ax[2][1] = rows[4 * WAVE]; o.ax[2][2] = rows[5 * WAVE];
-    } else if (o.kind == K_BOX) {
+    } else if (o.kind == K_BOX || o.kind == K_HULL) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             o.ax[j][0] = rows[(3 + 3 * j) * WAVE]; o.ax[j][1] = rows[(4 + 3 * j) * WAVE]; o.ax[j][2] = rows[(5 + 3 * j) * WAVE];
@@ -938,7 +938,7 @@ NBK_DEV void load_core_any(const DevModel& m, const double* lds_s, int ref, int 
         o.c[0] = rows[0]; o.c[1] = rows[WAVE]; o.c[2] = rows[2 * WAVE];
         if (o.kind == K_SEG || o.kind == K_CYL) {
             o.ax[2][0] = rows[3 * WAVE]; o.ax[2][1] = rows[4 * WAVE]; o.ax[2][2] = rows[5 * WAVE];
-        } else if (o.kind == K_BOX) {
+        } else if (o.kind == K_BOX || o.kind == K_HULL) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 o.ax[j][0] = rows[(3 + 3 * j) * WAVE]; o.ax[j][1] = rows[(4 + 3 * j) * WAVE]; o.ax[j][2] = rows[(5 + 3 * j) * WAVE];
@@ -1887,7 +1887,7 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
         xf_mul_pos(T, tl, o.c);
         if (o.kind == K_SEG || o.kind == K_CYL) {
             xf_mul_col(T, Rl, 2, o.ax[2]);
-        } else if (o.kind == K_BOX) {
+        } else if (o.kind == K_BOX || o.kind == K_HULL) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) xf_mul_col(T, Rl, j, o.ax[j]);
         }
@@ -2582,6 +2582,7 @@ static void core_params(int type, const double* param, int& kind, double* cc) {
             cc[0] = param[0] - param[3]; cc[1] = param[1] - param[3]; cc[2] = param[2] - param[3];
             break;
         case NBK_CYLINDER: kind = K_CYL; cc[4] = param[3]; cc[3] = param[0] - param[3]; cc[0] = param[1] - param[3]; break;
+        case NBK_HULL: kind = K_HULL; cc[4] = param[3]; break;      // cc[0..2] (the HullRef) and the radius are filled in by the caller
         default: kind = K_PLANE; break;
     }
 }
@@ -2593,11 +2594,22 @@ static double host_bound_radius(int kind, const double* cc) {
         case K_SEG: return cc[0];
         case K_CYL: return sqrt(fma(cc[3], cc[3], cc[0] * cc[0]));
         case K_BOX: return sqrt(fma(cc[2], cc[2], fma(cc[1], cc[1], cc[0] * cc[0])));
+        case K_HULL: return cc[5];                 // stored: hull_bound_radius of its vertices
         default: return HUGE_VAL;
     }
 }
 
-static int host_core_rows(int kind) { return kind == K_POINT ? 3 : (kind == K_BOX ? 12 : 6); }
+// largest vertex norm of a hull; must round exactly like the oracle's hull_bound_radius
+static double hull_bound_radius(const double* v, int n) {
+    double best = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double r2 = fma(v[3 * k + 2], v[3 * k + 2], fma(v[3 * k + 1], v[3 * k + 1], v[3 * k] * v[3 * k]));
+        if (r2 > best) best = r2;
+    }
+    return sqrt(best);
+}
+
+static int host_core_rows(int kind) { return kind == K_POINT ? 3 : ((kind == K_BOX || kind == K_HULL) ? 12 : 6); }
 
 }  // namespace nbk
 
@@ -2634,6 +2646,14 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     const int J = d->n_joints, S = d->n_rshapes, W = d->n_wshapes, P = d->n_pairs;
     if (d->n_q < 0 || J < 0 || S < 0 || W < 0 || P < 0) return NBK_ERR_INVALID;
     if (J > NBK_MAX_JOINTS || d->n_q > NBK_MAX_DOF) return NBK_ERR_UNSUPPORTED;
+    const int H = d->n_hulls;
+    if (H < 0 || (H > 0 && (d->hull_vert_begin == nullptr || d->hull_verts == nullptr || d->hull_face_begin == nullptr))) return NBK_ERR_INVALID;
+    for (int h = 0; h < H; ++h) {
+        if (d->hull_vert_begin[h + 1] <= d->hull_vert_begin[h] || d->hull_face_begin[h + 1] < d->hull_face_begin[h]) return NBK_ERR_INVALID;
+        if (h == 0 && (d->hull_vert_begin[0] != 0 || d->hull_face_begin[0] != 0)) return NBK_ERR_INVALID;
+    }
+    if (H > 0 && d->hull_face_begin[H] > 0 && d->hull_planes == nullptr) return NBK_ERR_INVALID;
+    auto hull_ok = [&](double idx) { return idx >= 0.0 && idx < (double)H && idx == (double)(int)idx; };
     for (int k = 0; k < J; ++k) {
         if (d->joint_parent[k] >= k || d->joint_parent[k] < -1) return NBK_ERR_INVALID;   // parents first
         if (d->joint_qidx[k] < 0 || d->joint_qidx[k] >= d->n_q) return NBK_ERR_INVALID;
@@ -2641,10 +2661,14 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     }
     for (int s = 0; s < S; ++s) {
         if (d->rshape_frame[s] < -1 || d->rshape_frame[s] >= J) return NBK_ERR_INVALID;
-        if (d->rshape_type[s] < NBK_SPHERE || d->rshape_type[s] > NBK_CYLINDER) return NBK_ERR_INVALID;
+        const int t = d->rshape_type[s];
+        if (!((t >= NBK_SPHERE && t <= NBK_CYLINDER) || t == NBK_HULL)) return NBK_ERR_INVALID;
+        if (t == NBK_HULL && !hull_ok(d->rshape_param[4 * s])) return NBK_ERR_INVALID;
     }
-    for (int w = 0; w < W; ++w)
-        if (d->wshape_type[w] < NBK_SPHERE || d->wshape_type[w] > NBK_PLANE) return NBK_ERR_INVALID;
+    for (int w = 0; w < W; ++w) {
+        if (d->wshape_type[w] < NBK_SPHERE || d->wshape_type[w] > NBK_HULL) return NBK_ERR_INVALID;
+        if (d->wshape_type[w] == NBK_HULL && !hull_ok(d->wshape_param[4 * w])) return NBK_ERR_INVALID;
+    }
     for (int p = 0; p < P; ++p) {
         if (d->pair_a[p] < 0 || d->pair_a[p] >= S) return NBK_ERR_INVALID;
         if (d->pair_b[p] < 0 || d->pair_b[p] >= S + W) return NBK_ERR_INVALID;
@@ -2672,12 +2696,18 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     std::vector<int> new_index(S);
     std::vector<int> rs_kind(S), rs_row(S);
     std::vector<double> rs_local(12 * (size_t)S), rs_core(6 * (size_t)S);
+    std::vector<int> rs_hull(S > 0 ? S : 1, -1), ws_hull(W > 0 ? W : 1, -1);      // hull index of K_HULL shapes
     int rows = 0;
     for (int i = 0; i < S; ++i) {
         const int s = order[i];
         new_index[s] = i;
         int kind;
         core_params(d->rshape_type[s], d->rshape_param + 4 * s, kind, &rs_core[6 * i]);
+        if (kind == K_HULL) {
+            const int h = (int)d->rshape_param[4 * s];
+            rs_core[6 * i + 5] = hull_bound_radius(d->hull_verts + 3 * (size_t)d->hull_vert_begin[h], d->hull_vert_begin[h + 1] - d->hull_vert_begin[h]);
+            rs_hull[i] = h;
+        }
         rs_core[6 * i + 5] = host_bound_radius(kind, &rs_core[6 * i]);
         rs_kind[i] = kind;
         rs_row[i] = rows;
@@ -2687,9 +2717,15 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     std::vector<int> ws_kind(W);
     std::vector<double> ws_core(18 * (size_t)W);
     for (int w = 0; w < W; ++w) {
-        double cc[5];
+        double cc[6];
         int kind;
         core_params(d->wshape_type[w], d->wshape_param + 4 * w, kind, cc);
+        cc[5] = 0.0;
+        if (kind == K_HULL) {
+            const int h = (int)d->wshape_param[4 * w];
+            cc[5] = hull_bound_radius(d->hull_verts + 3 * (size_t)d->hull_vert_begin[h], d->hull_vert_begin[h + 1] - d->hull_vert_begin[h]);
+            ws_hull[w] = h;
+        }
         ws_kind[w] = kind;
         const double* T = d->wshape_pose + 12 * w;
         double* o = &ws_core[18 * w];
@@ -2716,6 +2752,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         const int ka = kind_of(refA[p]), kb = kind_of(refB[p]);
         const bool a_ps = (ka == K_POINT || ka == K_SEG), b_ps = (kb == K_POINT || kb == K_SEG);
         if (kb == K_PLANE) vcls[p] = 0;
+        else if (ka == K_HULL || kb == K_HULL) vcls[p] = 2;           // hulls have no closed forms: GJK, also against a point
         else if ((a_ps && b_ps) || ka == K_POINT || kb == K_POINT) vcls[p] = 1;
         else vcls[p] = 2;
     }
@@ -2741,7 +2778,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         vp_cst[4 * i + 3] = host_bound_radius(kb, cb);
         {
             const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;          // canonical order
-            const bool closed = k0 == K_POINT || ((k0 == K_POINT || k0 == K_SEG) && (k1 == K_POINT || k1 == K_SEG));
+            const bool closed = k1 != K_HULL && (k0 == K_POINT || ((k0 == K_POINT || k0 == K_SEG) && (k1 == K_POINT || k1 == K_SEG)));
             if (k1 != K_PLANE && !closed && (ca[4] != 0.0 || cb[4] != 0.0)) margins_zero = false;
             if (k1 != K_PLANE && !closed) { gjk_margins.push_back(ca[4]); gjk_margins.push_back(cb[4]); }
         }
@@ -2926,11 +2963,27 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.rf = B.add(rs_frame_v.data(), sizeof(int) * S);
     o.bt = B.add(bq_tab.data(), sizeof(int) * 4 * P);
     o.bs = B.add(bq_static.data(), sizeof(double) * P);
+    const size_t o_hv = B.add(d->hull_verts, sizeof(double) * 3 * (size_t)(H > 0 ? d->hull_vert_begin[H] : 0));
+    const size_t o_hp = B.add(d->hull_planes, sizeof(double) * 4 * (size_t)(H > 0 ? d->hull_face_begin[H] : 0));
     B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
 
     void* dev = nullptr;
     hipError_t e = hipMalloc(&dev, B.bytes.size());
     if (e != hipSuccess) { delete M; hip_fail(e, "hipMalloc(model)"); return NBK_ERR_ALLOC; }
+    // hull shapes: their 24-byte h[] slots in the shape tables hold the device addresses of the hull's vertices / planes
+    {
+        auto patch = [&](size_t slot, int h) {
+            HullRef r;
+            r.hv = reinterpret_cast<const double*>(static_cast<const char*>(dev) + o_hv) + 3 * (size_t)d->hull_vert_begin[h];
+            r.hp = reinterpret_cast<const double*>(static_cast<const char*>(dev) + o_hp) + 4 * (size_t)d->hull_face_begin[h];
+            r.hn = d->hull_vert_begin[h + 1] - d->hull_vert_begin[h];
+            r.hf = d->hull_face_begin[h + 1] - d->hull_face_begin[h];
+            static_assert(sizeof(HullRef) == 24, "HullRef must overlay h[3]");
+            memcpy(B.bytes.data() + slot, &r, sizeof(r));
+        };
+        for (int i = 0; i < S; ++i) if (rs_hull[i] >= 0) patch(o.rc + sizeof(double) * 6 * (size_t)i, rs_hull[i]);
+        for (int w = 0; w < W; ++w) if (ws_hull[w] >= 0) patch(o.wc + sizeof(double) * (18 * (size_t)w + 12), ws_hull[w]);
+    }
     e = hipMemcpy(dev, B.bytes.data(), B.bytes.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(dev); delete M; return hip_fail(e, "hipMemcpy(model)"); }
     const char* base = static_cast<const char*>(dev);

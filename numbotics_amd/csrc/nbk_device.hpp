@@ -18,7 +18,9 @@
 
 namespace nbk {
 
-enum { K_POINT = 0, K_SEG = 1, K_BOX = 2, K_CYL = 3, K_PLANE = 4 };
+// K_HULL: convex hull of a vertex list in the primitive's local frame (MESH shapes: one hull per mesh object, which is what
+// the reference's GEOM_MESH collision shapes are in Bullet; numbotics/utils/shape.py:81-94, numbotics/utils/mesh.py:18-37).
+enum { K_POINT = 0, K_SEG = 1, K_BOX = 2, K_CYL = 3, K_HULL = 4, K_PLANE = 5 };
 
 // ---- small vectors ---------------------------------------------------------------------------
 NBK_DEV double dot3(const double* a, const double* b) { return NBK_FMA(a[2], b[2], NBK_FMA(a[1], b[1], a[0] * b[0])); }
@@ -101,12 +103,16 @@ NBK_DEV void nbk_sincos(double x, double& s, double& c) {
 }
 
 // ---- convex cores ------------------------------------------------------------------------------
-// shape = core (+) ball(margin):  sphere = point, capsule = segment, box, cylinder (axis = local z)
+// shape = core (+) ball(margin):  sphere = point, capsule = segment, box, cylinder (axis = local z), hull (vertex list)
+struct HullRef { const double* hv; const double* hp; int hn; int hf; };   // vertices [hn][3], face planes [hf][4] (n, d), local frame
 struct Core {
     int kind;            // wave-uniform
     double c[3];
-    double ax[3][3];     // ax[j] = world direction of local axis j (box: all three; seg/cyl: ax[2])
-    double h[3];         // uniform: seg/cyl h[0] = half length; box half extents
+    double ax[3][3];     // ax[j] = world direction of local axis j (box, hull: all three; seg/cyl: ax[2])
+    union {
+        double h[3];     // uniform: seg/cyl h[0] = half length; box half extents
+        HullRef hull;    // K_HULL: the same 24 bytes of the shape tables hold the hull's device pointers and counts
+    };
     double rad;          // uniform: cylinder radius
     double margin;       // uniform
     double rho;          // uniform: bounding radius of the core about c
@@ -133,6 +139,24 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
                 axpy3(k, w, o, o);
             }
         } break;
+        case K_HULL: {
+            // direction in local coordinates, first maximum over the vertex list, that vertex back to the world
+            const double dl0 = dot3(d, s.ax[0]), dl1 = dot3(d, s.ax[1]), dl2 = dot3(d, s.ax[2]);
+            const double* hv = s.hull.hv;
+            const int hn = s.hull.hn;
+            double best = -NBK_INF;
+            int bi = 0;
+            for (int k = 0; k < hn; ++k) {
+                const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
+                if (pr > best) { best = pr; bi = k; }
+            }
+            const double* v = hv + 3 * bi;
+            const double v0 = v[0], v1 = v[1], v2 = v[2];
+            copy3(s.c, o);
+            axpy3(v0, s.ax[0], o, o);
+            axpy3(v1, s.ax[1], o, o);
+            axpy3(v2, s.ax[2], o, o);
+        } break;
         default: {
             copy3(s.c, o);
 #pragma unroll
@@ -158,6 +182,22 @@ NBK_DEV double core_halfwidth(const Core& s, const double* n) {
             return NBK_FMA(s.h[2], __builtin_fabs(dot3(n, s.ax[2])),
                            NBK_FMA(s.h[1], __builtin_fabs(dot3(n, s.ax[1])), s.h[0] * __builtin_fabs(dot3(n, s.ax[0]))));
     }
+}
+
+// extents of a core along unit direction n about its centre: the core spans [-neg, +pos].  Symmetric kinds: both are the
+// half width; hull: pos = max_k dl.v_k, neg = -min_k dl.v_k with dl = n in local coordinates.
+NBK_DEV void core_extents(const Core& s, const double* n, double& neg, double& pos) {
+    if (s.kind != K_HULL) { const double hw = core_halfwidth(s, n); neg = hw; pos = hw; return; }
+    const double dl0 = dot3(n, s.ax[0]), dl1 = dot3(n, s.ax[1]), dl2 = dot3(n, s.ax[2]);
+    const double* hv = s.hull.hv;
+    const int hn = s.hull.hn;
+    double hi = -NBK_INF, lo = NBK_INF;
+    for (int k = 0; k < hn; ++k) {
+        const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
+        if (pr > hi) hi = pr;
+        if (pr < lo) lo = pr;
+    }
+    pos = hi; neg = -lo;
 }
 
 // ---- GJK ---------------------------------------------------------------------------------------
@@ -614,12 +654,36 @@ NBK_DEV void try_axis(const Core& A, const Core& Bc, const double* delta, const 
     const double inv = 1.0 / nbk_sqrt(nn);
     const double n[3] = {n_in[0] * inv, n_in[1] * inv, n_in[2] * inv};
     const double proj = dot3(n, delta);
+    if (A.kind == K_HULL || Bc.kind == K_HULL) {
+        // not centrally symmetric: pushing A along +n separates after tp = (aN + bP) - proj, along -n after tm = (aP + bN) + proj
+        double aN, aP, bN, bP;
+        core_extents(A, n, aN, aP);
+        core_extents(Bc, n, bN, bP);
+        const double tp = (aN + bP) - proj, tm = (aP + bN) + proj;
+        const double ov = tp <= tm ? tp : tm;
+        if (ov < best) {
+            best = ov;
+            const double sg = tp <= tm ? 1.0 : -1.0;
+            bn[0] = sg * n[0]; bn[1] = sg * n[1]; bn[2] = sg * n[2];
+        }
+        return;
+    }
     const double ov = (core_halfwidth(A, n) + core_halfwidth(Bc, n)) - __builtin_fabs(proj);
     if (ov < best) {
         best = ov;
         const double sg = proj >= 0.0 ? 1.0 : -1.0;
         bn[0] = sg * n[0]; bn[1] = sg * n[1]; bn[2] = sg * n[2];
     }
+}
+
+// world direction of face f of a hull core
+NBK_DEV void hull_face_normal(const Core& s, int f, double* n) {
+    const double* pl = s.hull.hp + 4 * f;
+    const double p0 = pl[0], p1 = pl[1], p2 = pl[2];
+    n[0] = 0.0; n[1] = 0.0; n[2] = 0.0;
+    axpy3(p0, s.ax[0], n, n);
+    axpy3(p1, s.ax[1], n, n);
+    axpy3(p2, s.ax[2], n, n);
 }
 
 NBK_DEV int core_naxes(const Core& s) { return s.kind == K_BOX ? 3 : ((s.kind == K_SEG || s.kind == K_CYL) ? 1 : 0); }
@@ -645,6 +709,9 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
                 cross3(core_axis(A, i), core_axis(Bc, j), cr);
                 try_axis(A, Bc, delta, cr, best, normal);
             }
+    // face normals of hull cores (exact for a point inside a hull, an upper bound otherwise: no edge-edge axes)
+    if (A.kind == K_HULL) for (int f = 0; f < A.hull.hf; ++f) { double fn[3]; hull_face_normal(A, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
+    if (Bc.kind == K_HULL) for (int f = 0; f < Bc.hull.hf; ++f) { double fn[3]; hull_face_normal(Bc, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
     if (A.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A.ax[2]), A.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
     if (Bc.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc.ax[2]), Bc.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
     try_axis(A, Bc, delta, delta, best, normal);
@@ -766,7 +833,8 @@ NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
         double d[3];
         sub3(A.c, Bc.c, d);
         const double hc = dot3(d, nn);
-        const double hw = core_halfwidth(A, nn);
+        double hw, hpos;
+        core_extents(A, nn, hw, hpos);         // how far the core reaches below its centre
         const double dist = (hc - hw) - A.margin;
         if constexpr (WIT) {
             const double neg[3] = {-nn[0], -nn[1], -nn[2]};
@@ -793,11 +861,11 @@ NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
                 else { n[0] = 1.0; n[1] = 0.0; n[2] = 0.0; }
             }
         }
-    } else if (A.kind == K_POINT) {
+    } else if (A.kind == K_POINT && Bc.kind != K_HULL) {
         double nb[3];
         dc = point_solid(A.c, Bc, pb, nb);
         copy3(A.c, pa); copy3(nb, n);
-    } else if (Bc.kind == K_POINT) {
+    } else if (Bc.kind == K_POINT && A.kind != K_HULL) {
         double na[3];
         dc = point_solid(Bc.c, A, pa, na);
         copy3(Bc.c, pb);
@@ -867,7 +935,9 @@ NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rh
     const double hc = dot3(d, Pl.ax[2]);
     const double t = thr + A.margin;
     if ((hc - rhoA) >= t) return false;            // broadphase: bounding sphere above the plane
-    return (hc - core_halfwidth(A, Pl.ax[2])) < t;
+    double hw, hpos;
+    core_extents(A, Pl.ax[2], hw, hpos);
+    return (hc - hw) < t;
 }
 
 // steps 4-5 of the predicate up to (not including) GJK: 0 = free, 1 = colliding, -1 = the GJK predicate decides.
@@ -888,7 +958,7 @@ NBK_DEV int cores_collide_pre(const Core& A, const Core& Bc, double tc) {
         sub3(pa, pb, e);
         return (nbk_sqrt(dot3(e, e)) < tc) ? 1 : 0;
     }
-    if (A.kind == K_POINT) { double cp[3], nb[3]; return (point_solid(A.c, Bc, cp, nb) < tc) ? 1 : 0; }
+    if (A.kind == K_POINT && Bc.kind != K_HULL) { double cp[3], nb[3]; return (point_solid(A.c, Bc, cp, nb) < tc) ? 1 : 0; }
     return -1;
 }
 

@@ -87,6 +87,11 @@ class DeviceModel:
             d.wshape_param = ptr(scene.wshape_param, np.float64)
             d.pair_a = ptr(scene.pair_a, np.int32)
             d.pair_b = ptr(scene.pair_b, np.int32)
+            d.n_hulls = scene.n_hulls
+            d.hull_vert_begin = ptr(scene.hull_vert_begin, np.int32)
+            d.hull_verts = ptr(scene.hull_verts, np.float64)
+            d.hull_face_begin = ptr(scene.hull_face_begin, np.int32)
+            d.hull_planes = ptr(scene.hull_planes, np.float64)
         h = C.c_void_p()
         _lib.check(lib.nbk_model_create(C.byref(d), C.byref(h)), "nbk_model_create")
         self._h = h

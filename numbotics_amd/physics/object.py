@@ -143,6 +143,11 @@ class Plane(PhysicsObject):
 
 
 class Mesh(PhysicsObject):
+    """Mesh obstacle (reference: physics/object.py:425-447).  Shape kwargs as upstream: ``mesh_scale``, ``offset``,
+    ``auto_center``, ``convex_decomposition``.  Collision geometry = one convex hull per object of the file (what Bullet's
+    GEOM_MESH is without the concave flag; numbotics_amd/utils/mesh.py); the file is read when the scene is compiled."""
     def __init__(self, mass: float, filename: str, static: bool = False, **kwargs):
-        raise NotImplementedError(
-            "MESH collision shapes are a SURVEY.md section 8(f) 'next' row (convex-hull ingestion); not built yet")
+        self._filename = filename
+        _static_mass_warning('Mesh', mass, static)
+        kwargs, shape_info = parse_shape_kwargs(kwargs)
+        super().__init__(mass, static, CollisionShape(Shape.MESH, filename=filename, **shape_info), None, **kwargs)

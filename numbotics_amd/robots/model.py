@@ -28,7 +28,7 @@ from numbotics_amd.physics import Constraint
 from numbotics_amd.utils import Shape
 
 # device / oracle shape type codes
-SH_SPHERE, SH_CAPSULE, SH_BOX, SH_CYLINDER, SH_PLANE = 0, 1, 2, 3, 4
+SH_SPHERE, SH_CAPSULE, SH_BOX, SH_CYLINDER, SH_PLANE, SH_HULL = 0, 1, 2, 3, 4, 5
 JT_REVOLUTE, JT_PRISMATIC = 0, 1
 MAX_JOINTS = 32
 
@@ -139,8 +139,50 @@ def compile_kinematics(chain) -> KinematicModel:
     return km
 
 
+class HullTable:
+    """Vertex / face-plane tables of the convex hulls of a scene (MESH shapes), shared by the device descriptor and the
+    oracle.  A shape of type SH_HULL names its hull in param[0]."""
+
+    def __init__(self):
+        self.verts, self.planes = [], []
+        self.vert_begin, self.face_begin = [0], [0]
+
+    def add(self, part) -> int:
+        self.verts.append(np.asarray(part.vertices, dtype=np.float64).reshape(-1, 3))
+        self.planes.append(np.asarray(part.planes, dtype=np.float64).reshape(-1, 4))
+        self.vert_begin.append(self.vert_begin[-1] + len(self.verts[-1]))
+        self.face_begin.append(self.face_begin[-1] + len(self.planes[-1]))
+        return len(self.verts) - 1
+
+    def arrays(self):
+        V = np.concatenate(self.verts) if self.verts else np.zeros((0, 3))
+        P = np.concatenate(self.planes) if self.planes else np.zeros((0, 4))
+        return (np.array(self.vert_begin, dtype=np.int32), np.ascontiguousarray(V, dtype=np.float64),
+                np.array(self.face_begin, dtype=np.int32), np.ascontiguousarray(P, dtype=np.float64))
+
+
+def _shape_records(cs, owner_pose_local: np.ndarray, hulls: HullTable):
+    """[(type, 3x4 pose in the owner frame, params[4])] for one CollisionShape: one record, except for a MESH, which
+    yields one convex hull per object of its file (numbotics/utils/shape.py:81-94 -> Bullet GEOM_MESH)."""
+    if cs.shape == Shape.MESH:
+        from numbotics_amd.utils.mesh import mesh_hulls
+        info = cs._shape_info
+        kw = {k: info[k] for k in ('mesh_scale', 'auto_center', 'convex_decomposition') if k in info}
+        T = owner_pose_local @ cs.offset
+        out = []
+        for part in mesh_hulls(info['filename'], **kw):
+            Tc = T.copy()
+            Tc[:3, 3] = T[:3, :3] @ part.center + T[:3, 3]          # the hull's local origin = the mean of its vertices
+            p = np.zeros(4)
+            p[0] = float(hulls.add(part))
+            p[3] = float(info.get('collision_margin', 0.0))
+            out.append((SH_HULL, Tc, p))
+        return out
+    return [_shape_record(cs, owner_pose_local)]
+
+
 def _shape_record(cs, owner_pose_local: np.ndarray):
-    """(type, 3x4 pose in the owner frame, params[4]) for one CollisionShape."""
+    """(type, 3x4 pose in the owner frame, params[4]) for one primitive CollisionShape."""
     info = cs._shape_info
     T = owner_pose_local @ cs.offset
     p = np.zeros(4)
@@ -162,8 +204,6 @@ def _shape_record(cs, owner_pose_local: np.ndarray):
         nw = T[:3, :3] @ (n / np.linalg.norm(n))
         p[0:3] = nw
         return SH_PLANE, T, p
-    if cs.shape == Shape.MESH:
-        raise NotImplementedError("MESH collision shapes: SURVEY.md section 8(f) 'next' row, not built yet")
     raise ValueError(f"shape {cs.shape} has no collision geometry")
 
 
@@ -184,6 +224,15 @@ class SceneModel:
     pair_b: np.ndarray                     # (P,) int32 robot shape, or S + world shape
     objects: list = field(default_factory=list)
     links: list = field(default_factory=list)
+    # convex hulls of MESH shapes (a shape of type SH_HULL names its hull in param[0])
+    hull_vert_begin: np.ndarray = field(default_factory=lambda: np.zeros(1, dtype=np.int32))
+    hull_verts: np.ndarray = field(default_factory=lambda: np.zeros((0, 3)))
+    hull_face_begin: np.ndarray = field(default_factory=lambda: np.zeros(1, dtype=np.int32))
+    hull_planes: np.ndarray = field(default_factory=lambda: np.zeros((0, 4)))
+
+    @property
+    def n_hulls(self):
+        return int(self.hull_vert_begin.shape[0]) - 1
 
     @property
     def n_rshapes(self):
@@ -212,6 +261,7 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
     links = chain._links
     link_index = {l._name: i for i, l in enumerate(links)}
     r_frame, r_type, r_local, r_param, r_link = [], [], [], [], []
+    hulls = HullTable()
     shapes_of_link = {}
     for i, link in enumerate(links):
         shapes = link._collision_shapes if compound else (
@@ -221,15 +271,15 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
         for cs in shapes:
             if cs.shape == Shape.EMPTY:
                 continue
-            t, T, p = _shape_record(cs, fr.local)
-            if t == SH_PLANE:
-                raise ValueError("a PLANE cannot be a robot link shape")
-            ids.append(len(r_type))
-            r_frame.append(fr.joint)
-            r_type.append(t)
-            r_local.append(_T34(T))
-            r_param.append(p)
-            r_link.append(i)
+            for t, T, p in _shape_records(cs, fr.local, hulls):
+                if t == SH_PLANE:
+                    raise ValueError("a PLANE cannot be a robot link shape")
+                ids.append(len(r_type))
+                r_frame.append(fr.joint)
+                r_type.append(t)
+                r_local.append(_T34(T))
+                r_param.append(p)
+                r_link.append(i)
         shapes_of_link[i] = ids
     S = len(r_type)
     objects, w_type, w_pose, w_param, w_obj = [], [], [], [], []
@@ -255,12 +305,12 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
             if key not in shapes_of_obj:
                 ids = []
                 if b._collision_shape.shape != Shape.EMPTY:
-                    t, T, p = _shape_record(b._collision_shape, b.pose)
-                    ids.append(len(w_type))
-                    w_type.append(t)
-                    w_pose.append(_T34(T))
-                    w_param.append(p)
-                    w_obj.append(len(objects))
+                    for t, T, p in _shape_records(b._collision_shape, b.pose, hulls):
+                        ids.append(len(w_type))
+                        w_type.append(t)
+                        w_pose.append(_T34(T))
+                        w_param.append(p)
+                        w_obj.append(len(objects))
                 objects.append(b)
                 shapes_of_obj[key] = ids
             for sa in shapes_of_link[ia]:
@@ -275,6 +325,7 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
         pa = np.array(pa, dtype=np.int32)[order]
         pb = np.array(pb, dtype=np.int32)[order]
     W = len(w_type)
+    hvb, hv, hfb, hp = hulls.arrays()
     return SceneModel(
         kin=kin,
         rshape_frame=np.array(r_frame, dtype=np.int32).reshape(S),
@@ -289,4 +340,5 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
         pair_a=np.array(pa, dtype=np.int32).reshape(-1),
         pair_b=np.array(pb, dtype=np.int32).reshape(-1),
         objects=objects, links=list(links),
+        hull_vert_begin=hvb, hull_verts=hv, hull_face_begin=hfb, hull_planes=hp,
     )

@@ -5,6 +5,11 @@ c2 : arm + one Cube(half_extent=0.4) at [1.0, 0.0, 0.2] (reference README.md:96)
      rule minus the hand removals of numbotics/tests/_test_rrt.py:38-61.
 c3 : arm + 8 Cube(half_extent=0.25) on a ring of radius 0.9 m, heights alternating 0.25 / 0.75 m, angles
      k*45 deg (build-defined: the reference has no 8-cube scene).
+c2m: c2 with the arm's collision primitives replaced by meshes (models/kinova_mesh.urdf: one convex hull per mesh object,
+     the bracelet link a two-object compound file).
+c5m: the mesh arm among mesh obstacles -- a rock (one hull), a table (compound: five objects in one OBJ), a wedge (binary
+     STL, scaled and rotated through the shape kwargs) and one Cube: BASELINE config 5's "compound-mesh collision shapes"
+     (build-defined layout: the reference ships no mesh scene, numbotics/tests/_test_manual.py:41 loads a single mesh body).
 The Kinova URDF is this build's own asset (numbotics_amd/models/kinova_cyl.urdf).
 """
 import os
@@ -13,6 +18,8 @@ from itertools import combinations
 import numpy as np
 
 KINOVA_URDF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "kinova_cyl.urdf")
+KINOVA_MESH_URDF = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "kinova_mesh.urdf")
+MESH_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", "meshes")
 
 _WRIST_GROUP = [
     'spherical_wrist_1_link', 'spherical_wrist_2_link', 'bracelet_link', 'end_effector_link', 'camera_link',
@@ -33,17 +40,28 @@ def apply_rrt_script_removals(arm):
         logger.VERBOSE = verbose
 
 
-def build_scene(name: str = "c2", urdf: str = KINOVA_URDF):
+def build_scene(name: str = "c2", urdf: str = None):
     """-> (arm, chain, obstacles).  Keep the returned obstacles alive: the world holds weak references."""
-    from numbotics_amd.physics import GraphChain, Cube
+    from numbotics_amd.physics import GraphChain, Cube, Mesh
     from numbotics_amd.robots import Arm
+    if urdf is None:
+        urdf = KINOVA_MESH_URDF if name in ("c2m", "c5m") else KINOVA_URDF
     chain = GraphChain.from_urdf(urdf)
     arm = Arm(chain)
     obstacles = []
     if name == "c1":
         pass
-    elif name == "c2":
+    elif name in ("c2", "c2m"):
         obstacles.append(Cube(half_extent=0.4, mass=0.0, position=np.array([1.0, 0.0, 0.2])))
+        apply_rrt_script_removals(arm)
+    elif name == "c5m":
+        from numbotics_amd.math import rpy_matrix, trans_mat
+        obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "rock.obj"), position=np.array([0.55, 0.25, 0.45])))
+        obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "table.obj"), position=np.array([0.0, -0.75, 0.0])))
+        obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "wedge.stl"), mesh_scale=np.array([1.5, 1.5, 1.2]),
+                              offset=trans_mat(pos=np.array([-0.1, -0.1, 0.0]), orn=rpy_matrix(np.array([0.0, 0.0, 0.6]))),
+                              position=np.array([-0.6, 0.35, 0.0])))
+        obstacles.append(Cube(half_extent=0.15, mass=0.0, position=np.array([0.45, -0.35, 0.85])))
         apply_rrt_script_removals(arm)
     elif name == "c3":
         for k in range(8):

@@ -35,6 +35,9 @@ class _Model(C.Structure):
         ("wshape_type", C.c_void_p), ("wshape_pose", C.c_void_p), ("wshape_param", C.c_void_p),
         ("n_pairs", C.c_int32),
         ("pair_a", C.c_void_p), ("pair_b", C.c_void_p),
+        ("n_hulls", C.c_int32),
+        ("hull_vert_begin", C.c_void_p), ("hull_verts", C.c_void_p),
+        ("hull_face_begin", C.c_void_p), ("hull_planes", C.c_void_p),
     ]
 
 
@@ -96,6 +99,11 @@ class Oracle:
             m.wshape_param = keep(sc.wshape_param, np.float64)
             m.pair_a = keep(sc.pair_a, np.int32)
             m.pair_b = keep(sc.pair_b, np.int32)
+            m.n_hulls = sc.n_hulls
+            m.hull_vert_begin = keep(sc.hull_vert_begin, np.int32)
+            m.hull_verts = keep(sc.hull_verts, np.float64)
+            m.hull_face_begin = keep(sc.hull_face_begin, np.int32)
+            m.hull_planes = keep(sc.hull_planes, np.float64)
         self._m = m
         self.n_q = kin.n_q
         self.n_pairs = sc.n_pairs if sc is not None else 0
@@ -231,3 +239,51 @@ def shape_collides(type_a, pose_a, param_a, type_b, pose_b, param_b, threshold=0
     qa, qb = _f64(param_a, (4,)), _f64(param_b, (4,))
     return bool(lib().orc_shape_collides(C.c_int32(type_a), _p(pa), _p(qa), C.c_int32(type_b), _p(pb), _p(qb),
                                          C.c_double(threshold)))
+
+
+class HullSet:
+    """Hull tables for ``shape_distance`` / ``shape_collides`` on single shape pairs: ``add(part)`` returns the index a
+    shape of type 5 (hull) puts into param[0].  ``part``: numbotics_amd.utils.mesh.ConvexPart (data only)."""
+
+    def __init__(self):
+        self._v, self._p, self._vb, self._fb = [], [], [0], [0]
+        self._m = None
+
+    def add(self, part) -> int:
+        self._v.append(_f64(part.vertices, (-1, 3)))
+        self._p.append(_f64(part.planes, (-1, 4)))
+        self._vb.append(self._vb[-1] + len(self._v[-1]))
+        self._fb.append(self._fb[-1] + len(self._p[-1]))
+        self._m = None
+        return len(self._v) - 1
+
+    def model(self):
+        if self._m is None:
+            m = _Model()
+            self._keep = [np.array(self._vb, dtype=np.int32), _f64(np.concatenate(self._v)),
+                          np.array(self._fb, dtype=np.int32), _f64(np.concatenate(self._p))]
+            m.n_hulls = len(self._v)
+            m.hull_vert_begin, m.hull_verts, m.hull_face_begin, m.hull_planes = [a.ctypes.data for a in self._keep]
+            self._m = m
+        return self._m
+
+
+def shape_distance_h(hulls, type_a, pose_a, param_a, type_b, pose_b, param_b):
+    """``shape_distance`` with hull shapes (type 5, param[0] = index into ``hulls``)."""
+    pa = _f64(np.asarray(pose_a)[:3, :4]).reshape(12)
+    pb = _f64(np.asarray(pose_b)[:3, :4]).reshape(12)
+    qa, qb = _f64(param_a, (4,)), _f64(param_b, (4,))
+    wit = np.empty((9,))
+    it = C.c_int32(0)
+    f = lib().orc_shape_distance_m
+    f.restype = C.c_double
+    d = f(C.byref(hulls.model()), C.c_int32(type_a), _p(pa), _p(qa), C.c_int32(type_b), _p(pb), _p(qb), _p(wit), C.byref(it))
+    return float(d), wit[0:3].copy(), wit[3:6].copy(), wit[6:9].copy(), int(it.value)
+
+
+def shape_collides_h(hulls, type_a, pose_a, param_a, type_b, pose_b, param_b, threshold=0.0):
+    pa = _f64(np.asarray(pose_a)[:3, :4]).reshape(12)
+    pb = _f64(np.asarray(pose_b)[:3, :4]).reshape(12)
+    qa, qb = _f64(param_a, (4,)), _f64(param_b, (4,))
+    return bool(lib().orc_shape_collides_m(C.byref(hulls.model()), C.c_int32(type_a), _p(pa), _p(qa), C.c_int32(type_b),
+                                           _p(pb), _p(qb), C.c_double(threshold)))

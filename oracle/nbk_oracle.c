@@ -332,7 +332,11 @@ int orc_ik(const orc_model *m, const double *pose, const double *q0, int64_t B, 
  * axis family below (exact MTD for point/segment/box cores, an upper bound when a cylinder core is
  * involved).
  * ---------------------------------------------------------------------------------------------- */
-enum { K_POINT = 0, K_SEG = 1, K_BOX = 2, K_CYL = 3, K_PLANE = 4 };
+/* K_HULL: convex hull of a vertex list given in the primitive's local frame (MESH shapes: numbotics/utils/shape.py:81-94
+ * hands the mesh file to pybullet.createCollisionShape(GEOM_MESH), which -- without the concave-trimesh flag the reference
+ * never sets -- builds one convex hull per OBJ object; numbotics/utils/mesh.py:18-37 scales / offsets the vertices first).
+ * The local origin is the mean of the hull's vertices (an interior point), rho = the largest vertex norm. */
+enum { K_POINT = 0, K_SEG = 1, K_BOX = 2, K_CYL = 3, K_HULL = 4, K_PLANE = 5 };
 
 typedef struct {
     int kind;
@@ -341,13 +345,36 @@ typedef struct {
     double h[3];     /* seg: h[0] = half length; cyl: h[0] = half height; box: half extents (core) */
     double rad;      /* cyl core radius */
     double margin;
+    const double *hv; int hn;   /* hull: vertices [hn][3] (local) */
+    const double *hp; int hf;   /* hull: face planes [hf][4] = unit outward normal, offset (local): inside n.x <= d */
+    double rho;                 /* hull: bounding radius about c */
 } core_t;
 
-static void core_from_shape(int type, const xf_t *pose, const double *param, core_t *o) {
+/* largest vertex norm, rounded like the device's host code: sqrt(max_k fma(z,z,fma(y,y,x*x))) */
+static double hull_bound_radius(const double *v, int n) {
+    double best = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double r2 = FMA(v[3 * k + 2], v[3 * k + 2], FMA(v[3 * k + 1], v[3 * k + 1], v[3 * k] * v[3 * k]));
+        if (r2 > best) best = r2;
+    }
+    return sqrt(best);
+}
+
+static void core_from_shape(const orc_model *m, int type, const xf_t *pose, const double *param, core_t *o) {
     o->c[0] = pose->t[0]; o->c[1] = pose->t[1]; o->c[2] = pose->t[2];
     for (int j = 0; j < 3; ++j) { o->ax[j][0] = pose->R[j]; o->ax[j][1] = pose->R[3 + j]; o->ax[j][2] = pose->R[6 + j]; }
     o->h[0] = o->h[1] = o->h[2] = 0.0; o->rad = 0.0; o->margin = 0.0;
+    o->hv = NULL; o->hn = 0; o->hp = NULL; o->hf = 0; o->rho = 0.0;
     switch (type) {
+        case ORC_HULL: {
+            const int h = (int)param[0];
+            o->kind = K_HULL; o->margin = param[3];
+            o->hv = m->hull_verts + 3 * (size_t)m->hull_vert_begin[h];
+            o->hn = m->hull_vert_begin[h + 1] - m->hull_vert_begin[h];
+            o->hp = m->hull_planes + 4 * (size_t)m->hull_face_begin[h];
+            o->hf = m->hull_face_begin[h + 1] - m->hull_face_begin[h];
+            o->rho = hull_bound_radius(o->hv, o->hn);
+        } break;
         case ORC_SPHERE: o->kind = K_POINT; o->margin = param[0]; break;
         case ORC_CAPSULE: o->kind = K_SEG; o->margin = param[0]; o->h[0] = param[1]; break;
         case ORC_BOX:
@@ -389,6 +416,20 @@ static void core_support(const core_t *s, const double *d, double *o) {
                 axpy3(k, w, o, o);
             }
         } break;
+        case K_HULL: {
+            /* direction in local coordinates, first maximum over the vertex list, vertex back to the world */
+            const double dl[3] = {dot3(d, s->ax[0]), dot3(d, s->ax[1]), dot3(d, s->ax[2])};
+            double best = -INFINITY;
+            int bi = 0;
+            for (int k = 0; k < s->hn; ++k) {
+                const double *v = s->hv + 3 * k;
+                const double pr = FMA(v[2], dl[2], FMA(v[1], dl[1], v[0] * dl[0]));
+                if (pr > best) { best = pr; bi = k; }
+            }
+            const double *v = s->hv + 3 * bi;
+            o[0] = s->c[0]; o[1] = s->c[1]; o[2] = s->c[2];
+            for (int j = 0; j < 3; ++j) axpy3(v[j], s->ax[j], o, o);
+        } break;
         default: { /* box */
             o[0] = s->c[0]; o[1] = s->c[1]; o[2] = s->c[2];
             for (int j = 0; j < 3; ++j) {
@@ -413,6 +454,21 @@ static double core_halfwidth(const core_t *s, const double *n) {
         default:
             return FMA(s->h[2], fabs(dot3(n, s->ax[2])), FMA(s->h[1], fabs(dot3(n, s->ax[1])), s->h[0] * fabs(dot3(n, s->ax[0]))));
     }
+}
+
+/* extents of a core along unit direction n, measured from its centre c: the core spans [-neg, +pos].
+ * Symmetric kinds: neg = pos = halfwidth; hull: pos = max_k dl.v_k, neg = -min_k dl.v_k (dl = n in local coordinates). */
+static void core_extents(const core_t *s, const double *n, double *neg, double *pos) {
+    if (s->kind != K_HULL) { const double hw = core_halfwidth(s, n); *neg = hw; *pos = hw; return; }
+    const double dl[3] = {dot3(n, s->ax[0]), dot3(n, s->ax[1]), dot3(n, s->ax[2])};
+    double hi = -INFINITY, lo = INFINITY;
+    for (int k = 0; k < s->hn; ++k) {
+        const double *v = s->hv + 3 * k;
+        const double pr = FMA(v[2], dl[2], FMA(v[1], dl[1], v[0] * dl[0]));
+        if (pr > hi) hi = pr;
+        if (pr < lo) lo = pr;
+    }
+    *pos = hi; *neg = -lo;
 }
 
 /* ---- GJK on cores -------------------------------------------------------------------------- */
@@ -658,12 +714,34 @@ static void try_axis(const core_t *A, const core_t *Bc, const double *delta, con
     const double inv = 1.0 / sqrt(nn);
     double n[3] = {n_in[0] * inv, n_in[1] * inv, n_in[2] * inv};
     const double proj = dot3(n, delta); /* delta = cA - cB */
+    if (A->kind == K_HULL || Bc->kind == K_HULL) {
+        /* not centrally symmetric: A spans [-aN, aP], B spans [-bN, bP] about their centres along n.  Pushing A along +n
+         * separates after tp = (aN + bP) - proj, along -n after tm = (aP + bN) + proj; the smaller one is the overlap. */
+        double aN, aP, bN, bP;
+        core_extents(A, n, &aN, &aP);
+        core_extents(Bc, n, &bN, &bP);
+        const double tp = (aN + bP) - proj, tm = (aP + bN) + proj;
+        const double ov = tp <= tm ? tp : tm;
+        if (ov < *best) {
+            *best = ov;
+            const double sg = tp <= tm ? 1.0 : -1.0;
+            bn[0] = sg * n[0]; bn[1] = sg * n[1]; bn[2] = sg * n[2];
+        }
+        return;
+    }
     const double ov = (core_halfwidth(A, n) + core_halfwidth(Bc, n)) - fabs(proj);
     if (ov < *best) {
         *best = ov;
         const double sg = proj >= 0.0 ? 1.0 : -1.0; /* normal from B to A */
         bn[0] = sg * n[0]; bn[1] = sg * n[1]; bn[2] = sg * n[2];
     }
+}
+
+/* world direction of face f of a hull core */
+static void hull_face_normal(const core_t *s, int f, double *n) {
+    const double *pl = s->hp + 4 * f;
+    n[0] = 0.0; n[1] = 0.0; n[2] = 0.0;
+    for (int j = 0; j < 3; ++j) axpy3(pl[j], s->ax[j], n, n);
 }
 
 static int core_axes(const core_t *s, const double **ax) {
@@ -687,6 +765,10 @@ static double overlap_depth(const core_t *A, const core_t *Bc, double *normal) {
             cross3(aa[i], ba[j], cr);
             try_axis(A, Bc, delta, cr, &best, normal);
         }
+    /* face normals of hull cores (exact depth for a point inside a hull; an upper bound otherwise: edge-edge axes are
+     * not tried) */
+    if (A->kind == K_HULL) for (int f = 0; f < A->hf; ++f) { double fn[3]; hull_face_normal(A, f, fn); try_axis(A, Bc, delta, fn, &best, normal); }
+    if (Bc->kind == K_HULL) for (int f = 0; f < Bc->hf; ++f) { double fn[3]; hull_face_normal(Bc, f, fn); try_axis(A, Bc, delta, fn, &best, normal); }
     /* radial directions of cylinder cores, and the centre line */
     if (A->kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A->ax[2]), A->ax[2], delta, r); try_axis(A, Bc, delta, r, &best, normal); }
     if (Bc->kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc->ax[2]), Bc->ax[2], delta, r); try_axis(A, Bc, delta, r, &best, normal); }
@@ -805,7 +887,8 @@ static double cores_distance(const core_t *A, const core_t *Bc, double *wit, int
         double d[3];
         sub3(A->c, Bc->c, d);
         const double hc = dot3(d, nn);
-        const double hw = core_halfwidth(A, nn);
+        double hw, hpos;
+        core_extents(A, nn, &hw, &hpos);       /* how far the core reaches below its centre */
         const double dist = (hc - hw) - A->margin;
         if (wit) {
             double neg[3] = {-nn[0], -nn[1], -nn[2]};
@@ -830,12 +913,12 @@ static double cores_distance(const core_t *A, const core_t *Bc, double *wit, int
             if (A->kind == K_SEG && Bc->kind == K_SEG && cc > 1e-24) { const double inv = 1.0 / sqrt(cc); n[0] = cr[0] * inv; n[1] = cr[1] * inv; n[2] = cr[2] * inv; }
             else { n[0] = 1.0; n[1] = 0.0; n[2] = 0.0; }
         }
-    } else if (A->kind == K_POINT) {
+    } else if (A->kind == K_POINT && Bc->kind != K_HULL) {
         double nb[3];
         dc = point_solid(A->c, Bc, pb, nb);
         memcpy(pa, A->c, 24);
         n[0] = nb[0]; n[1] = nb[1]; n[2] = nb[2];
-    } else if (Bc->kind == K_POINT) {
+    } else if (Bc->kind == K_POINT && A->kind != K_HULL) {
         double na[3];
         dc = point_solid(Bc->c, A, pa, na);
         memcpy(pb, Bc->c, 24);
@@ -980,6 +1063,7 @@ static double core_bound_radius(const core_t *s) {
         case K_SEG: return s->h[0];
         case K_CYL: return sqrt(FMA(s->rad, s->rad, s->h[0] * s->h[0]));
         case K_BOX: return sqrt(FMA(s->h[2], s->h[2], FMA(s->h[1], s->h[1], s->h[0] * s->h[0])));
+        case K_HULL: return s->rho;
         default: return INFINITY;
     }
 }
@@ -1005,7 +1089,9 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
         const double hc = dot3(d, B0->ax[2]);
         const double t = thr + A0->margin;
         if ((hc - core_bound_radius(A0)) >= t) return 0;       /* broadphase: bounding sphere above the plane */
-        return (hc - core_halfwidth(A0, B0->ax[2])) < t;
+        double hw, hpos;
+        core_extents(A0, B0->ax[2], &hw, &hpos);
+        return (hc - hw) < t;
     }
     const double tc = (thr + A0->margin) + B0->margin;
     const double rs = (tc + core_bound_radius(A0)) + core_bound_radius(B0);
@@ -1052,7 +1138,7 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
         sub3(pa, pb, e);
         return sqrt(dot3(e, e)) < tc;
     }
-    if (A->kind == K_POINT) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
+    if (A->kind == K_POINT && Bc->kind != K_HULL) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
     g_stat_gjk++;
     if (tc == 0.0) return gjk_intersect(A, Bc);      /* pure intersection test: the boolean walk */
     return gjk_collides(A, Bc, tc);
@@ -1063,17 +1149,22 @@ void orc_stats(long long *out, int reset) {
     if (reset) { g_stat_items = g_stat_survive = g_stat_gjk = 0; }
 }
 
-double orc_shape_distance(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
-                          const double *pose_b, const double *param_b, double *witness, int32_t *iters) {
+double orc_shape_distance_m(const orc_model *hulls, int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                            const double *pose_b, const double *param_b, double *witness, int32_t *iters) {
     xf_t xa, xb;
     core_t A, Bc;
     xf_from12(pose_a, &xa); xf_from12(pose_b, &xb);
-    core_from_shape(type_a, &xa, param_a, &A);
-    core_from_shape(type_b, &xb, param_b, &Bc);
+    core_from_shape(hulls, type_a, &xa, param_a, &A);
+    core_from_shape(hulls, type_b, &xb, param_b, &Bc);
     int it = 0;
     const double d = cores_distance(&A, &Bc, witness, &it);
     if (iters) *iters = it;
     return d;
+}
+
+double orc_shape_distance(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                          const double *pose_b, const double *param_b, double *witness, int32_t *iters) {
+    return orc_shape_distance_m(NULL, type_a, pose_a, param_a, type_b, pose_b, param_b, witness, iters);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1086,7 +1177,7 @@ static core_t *build_world_cores(const orc_model *m) {
     for (int i = 0; i < m->n_wshapes; ++i) {
         xf_t x;
         xf_from12(m->wshape_pose + 12 * i, &x);
-        core_from_shape(m->wshape_type[i], &x, m->wshape_param + 4 * i, &w[i]);
+        core_from_shape(m, m->wshape_type[i], &x, m->wshape_param + 4 * i, &w[i]);
     }
     return w;
 }
@@ -1104,7 +1195,7 @@ static void robot_cores(const orc_model *m, const double *q, xf_t *frames, core_
         xf_t loc, W;
         xf_from12(m->rshape_local + 12 * s, &loc);
         xf_mul(F, loc.R, loc.t, &W);
-        core_from_shape(m->rshape_type[s], &W, m->rshape_param + 4 * s, &rc[s]);
+        core_from_shape(m, m->rshape_type[s], &W, m->rshape_param + 4 * s, &rc[s]);
     }
 }
 
@@ -1346,12 +1437,17 @@ int orc_edge_validity(const orc_model *m, const double *starts, const double *go
     return 0;
 }
 
-int orc_shape_collides(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
-                       const double *pose_b, const double *param_b, double threshold) {
+int orc_shape_collides_m(const orc_model *hulls, int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                         const double *pose_b, const double *param_b, double threshold) {
     xf_t xa, xb;
     core_t A, Bc;
     xf_from12(pose_a, &xa); xf_from12(pose_b, &xb);
-    core_from_shape(type_a, &xa, param_a, &A);
-    core_from_shape(type_b, &xb, param_b, &Bc);
+    core_from_shape(hulls, type_a, &xa, param_a, &A);
+    core_from_shape(hulls, type_b, &xb, param_b, &Bc);
     return cores_collide(&A, &Bc, threshold);
+}
+
+int orc_shape_collides(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                       const double *pose_b, const double *param_b, double threshold) {
+    return orc_shape_collides_m(NULL, type_a, pose_a, param_a, type_b, pose_b, param_b, threshold);
 }

@@ -10,6 +10,9 @@
  *   - validity predicate        numbotics/robots/arm.py:599-604  (min signed distance < threshold, strict)
  *   - edge discretisation       numbotics/planning/sampling_based/connectors.py:57-100,
  *                               numbotics/planning/trajectories.py:6-22
+ *   - MESH shapes               numbotics/utils/mesh.py:18-37, numbotics/utils/shape.py:81-94: one convex hull per mesh
+ *                               object (what GEOM_MESH without the concave flag is in Bullet); hull building itself is host
+ *                               Python (numbotics_amd/utils/mesh.py), the oracle consumes vertex / face-plane tables
  *   - link-pair signed distance pybullet 3.2.7 getClosestPoints (numbotics/physics/chain.py:944-951);
  *                               Bullet's source is NOT under /root/reference and pybullet is not
  *                               installed: PARITY UNPINNED for every distance value.  The semantics
@@ -28,7 +31,7 @@
 extern "C" {
 #endif
 
-enum { ORC_SPHERE = 0, ORC_CAPSULE = 1, ORC_BOX = 2, ORC_CYLINDER = 3, ORC_PLANE = 4 };
+enum { ORC_SPHERE = 0, ORC_CAPSULE = 1, ORC_BOX = 2, ORC_CYLINDER = 3, ORC_PLANE = 4, ORC_HULL = 5 };
 enum { ORC_REVOLUTE = 0, ORC_PRISMATIC = 1 };
 
 typedef struct {
@@ -54,6 +57,14 @@ typedef struct {
     int32_t n_pairs;
     const int32_t *pair_a;        /* [P] robot shape */
     const int32_t *pair_b;        /* [P] robot shape, or S + world shape */
+    /* convex hulls of MESH shapes (numbotics/utils/shape.py:81-94, numbotics/utils/mesh.py:18-37): a shape of type ORC_HULL
+     * names its hull in param[0]; vertices / face planes are in the primitive's local frame, whose origin is the mean of
+     * the hull's vertices; param[3] = margin (inflates the hull, as Bullet's margin does for btConvexHullShape) */
+    int32_t n_hulls;
+    const int32_t *hull_vert_begin;  /* [H+1] */
+    const double *hull_verts;        /* [NV][3] */
+    const int32_t *hull_face_begin;  /* [H+1] */
+    const double *hull_planes;       /* [NF][4] unit outward normal n and offset d: inside n.x <= d */
 } orc_model;
 
 void orc_sincos(double x, double *s, double *c);
@@ -106,6 +117,12 @@ int orc_edge_samples(int32_t n_q, const double *start, const double *goal, doubl
 double orc_shape_distance(int32_t type_a, const double *pose_a, const double *param_a,
                           int32_t type_b, const double *pose_b, const double *param_b,
                           double *witness, int32_t *iters);
+
+/* the same with hull shapes: `hulls` carries the hull tables (only the hull_* fields are read) */
+double orc_shape_distance_m(const orc_model *hulls, int32_t type_a, const double *pose_a, const double *param_a,
+                            int32_t type_b, const double *pose_b, const double *param_b, double *witness, int32_t *iters);
+int orc_shape_collides_m(const orc_model *hulls, int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
+                         const double *pose_b, const double *param_b, double threshold);
 
 /* broadphase statistics of the predicate since the last reset: items, survivors of the sphere test, GJK calls
  * (single-threaded runs only; not synchronised) */

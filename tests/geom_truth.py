@@ -7,7 +7,7 @@ Only meaningful when the cores are disjoint (positive core distance).
 import numpy as np
 from scipy.optimize import minimize
 
-SPHERE, CAPSULE, BOX, CYLINDER, PLANE = 0, 1, 2, 3, 4
+SPHERE, CAPSULE, BOX, CYLINDER, PLANE, HULL = 0, 1, 2, 3, 4, 5
 
 
 def random_pose(rng, scale=0.5):
@@ -43,6 +43,8 @@ def _core(t, p):
         return ("box", p[:3] - p[3]), p[3]
     if t == CYLINDER:
         return ("cyl", (p[0] - p[3], p[1] - p[3])), p[3]
+    if t == HULL:
+        return ("hull", p[4]), p[3]          # p[4] = (vertices (m,3), planes (f,4)) of a ConvexPart, p[3] = margin
     raise ValueError(t)
 
 
@@ -55,6 +57,16 @@ def _bounds_cons(kind, data, off):
         b = [(0, 0), (0, 0), (-data, data)]
     elif kind == "box":
         b = [(-data[0], data[0]), (-data[1], data[1]), (-data[2], data[2])]
+    elif kind == "hull":
+        V, P = data
+        lo, hi = V.min(axis=0), V.max(axis=0)
+        b = [(lo[0], hi[0]), (lo[1], hi[1]), (lo[2], hi[2])]
+        for pl in P:               # the H-representation: n.x <= d for every face (independent of the vertex list GJK uses)
+            def jac(z, o=off, pl=pl):
+                g = np.zeros(len(z))
+                g[o:o + 3] = -pl[:3]
+                return g
+            cons.append({'type': 'ineq', 'fun': lambda z, o=off, pl=pl: pl[3] - pl[:3] @ z[o:o + 3], 'jac': jac})
     else:
         R, h = data
         b = [(-R, R), (-R, R), (-h, h)]

@@ -2,11 +2,34 @@
 import numpy as np
 
 
-def random_urdf(rng, n_links, path, max_back=3):
+def random_hull_obj(rng, path, n_objects=1, scale=0.1):
+    """A mesh file of ``n_objects`` random convex polytopes (one OBJ object each)."""
+    from numbotics_amd.utils.mesh import write_obj, hull_faces
+    parts = []
+    for i in range(n_objects):
+        n = int(rng.integers(6, 28))
+        pts = rng.normal(size=(n, 3))
+        pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0.5, 1.0, (n, 1)) * rng.uniform(0.3, 1.0, 3) * scale
+        V, F = hull_faces(pts + rng.uniform(-scale, scale, 3) * (i > 0))
+        parts.append((f"part{i}", V, F))
+    return write_obj(path, parts)
+
+
+def random_urdf(rng, n_links, path, max_back=3, meshes=False):
     """A random tree of n_links links: revolute / continuous / prismatic / fixed joints with random origins and
-    axes, every link carrying 0-2 collision primitives (box / sphere / cylinder / capsule)."""
+    axes, every link carrying 0-2 collision primitives (box / sphere / cylinder / capsule; with ``meshes`` also <mesh>
+    elements -- random convex polytopes, some files holding two objects -- written next to the URDF)."""
+    import os
+    mesh_no = [0]
+
     def geom():
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 6 if meshes else 4)
+        if kind >= 4:
+            fn = f"fuzz_mesh_{mesh_no[0]}.obj"
+            mesh_no[0] += 1
+            random_hull_obj(rng, os.path.join(os.path.dirname(path), fn), n_objects=int(rng.choice([1, 1, 2])), scale=0.08)
+            sc = "" if rng.random() < 0.5 else f' scale="{rng.uniform(0.6, 1.4):.3f} {rng.uniform(0.6, 1.4):.3f} {rng.uniform(0.6, 1.4):.3f}"'
+            return f'<mesh filename="{fn}"{sc}/>'
         if kind == 0:
             s = rng.uniform(0.04, 0.16, 3)
             return f'<box size="{s[0]:.4f} {s[1]:.4f} {s[2]:.4f}"/>'
@@ -44,12 +67,27 @@ def random_urdf(rng, n_links, path, max_back=3):
     return path
 
 
-def random_obstacles(rng, n, reach=0.9):
+def random_obstacles(rng, n, reach=0.9, mesh_dir=None):
+    """``mesh_dir``: also Mesh obstacles (random polytope files written there; shape kwargs exercised at random)."""
     from geom_truth import random_pose
-    from numbotics_amd.physics import Cube, Cuboid, Sphere, Capsule, Cylinder, Plane
+    from numbotics_amd.physics import Cube, Cuboid, Sphere, Capsule, Cylinder, Plane, Mesh
+    import os
     obs = []
-    for _ in range(n):
-        k = int(rng.integers(0, 6))
+    for i in range(n):
+        k = int(rng.integers(0, 9 if mesh_dir is not None else 6))
+        if k >= 6:
+            fn = random_hull_obj(rng, os.path.join(mesh_dir, f"fuzz_obstacle_{i}.obj"), n_objects=int(rng.choice([1, 2, 3])), scale=0.15)
+            kw = {}
+            if rng.random() < 0.5:
+                kw['mesh_scale'] = rng.uniform(0.5, 1.5, 3)
+            if rng.random() < 0.5:
+                kw['offset'] = random_pose(rng, 0.1)
+            if rng.random() < 0.3:
+                kw['auto_center'] = True
+            if rng.random() < 0.3:
+                kw['collision_margin'] = float(rng.choice([0.005, 0.02]))
+            obs.append(Mesh(0.0, fn, pose=random_pose(rng, reach), **kw))
+            continue
         pose = random_pose(rng, reach)
         margin = float(rng.choice([0.0, 0.0, 0.01, 0.03]))
         if k == 0:

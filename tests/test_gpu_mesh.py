@@ -1,0 +1,174 @@
+"""GPU parity for MESH collision shapes (BASELINE config 5): a robot whose links carry mesh
+hulls (one compound two-object file among them) among mesh obstacles (single hull, five-object compound, binary STL with
+scale / offset kwargs) -- every entry point through the C-ABI, bit for bit against the CPU oracle.  The hull geometry the
+oracle defines is pinned on the CPU side (tests/test_mesh.py: SLSQP over the hulls' face planes); Bullet itself is
+third-party and absent: PARITY WITH getClosestPoints ON MESHES IS UNPINNED."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.cpu_oracle import Oracle
+from numbotics_amd.scenes import build_scene, sample_q
+from test_gpu_parity import assert_bitwise, fused_path, torch_cuda      # noqa: F401  (fixture)
+
+
+@pytest.mark.parametrize("scene", ["c2m", "c5m"])
+def test_mesh_validity_through_all_three_paths(fresh_world, scene, torch_cuda):
+    import os
+    torch = torch_cuda
+    arm, chain, obs = build_scene(scene)
+    sm = arm.scene_model()
+    assert (sm.rshape_type == 5).sum() == 10
+    orc = Oracle(sm)
+    _, dev = arm._scene_device()
+    q = sample_q(chain, 20000, seed=2)
+    for thr in (0.0, 1e-6, 0.02, -0.005):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref), (scene, thr, "float32 broadphase + narrowphase")
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:4096], thr), ref[:4096]), (scene, thr, "fused kernel")
+        os.environ["NBK_F64_BROAD"] = "1"
+        try:
+            assert np.array_equal(arm.in_collision(q, thr), ref), (scene, thr, "float64 broadphase")
+        finally:
+            del os.environ["NBK_F64_BROAD"]
+    ref0 = orc.validity(q, 0.0, nthreads=8)
+    assert 0.03 < ref0.mean() < 0.6
+    need = dev.validity_workspace_bytes(20000)
+    ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+    assert np.array_equal(dev.validity(q, 0.0, workspace=ws), ref0)                       # caller-owned workspace
+    for B in (1, 63, 64, 65, 130):
+        assert np.array_equal(arm.in_collision(q[:B]), ref0[:B])
+    assert isinstance(arm.in_collision(q[0]), bool) and arm.in_collision(q[0]) == bool(ref0[0])
+
+
+@pytest.mark.parametrize("scene", ["c2m", "c5m"])
+def test_mesh_distances_witnesses_and_proximity_rows(fresh_world, scene, torch_cuda):
+    """BASELINE config 5 on mesh shapes: M = 10 071 samples (numbotics/planning/safe_sets.py:176-182), per sample every
+    pair's signed distance, contact points, normal and (P,7) proximity-Jacobian row (numbotics/robots/arm.py:607-632)."""
+    arm, chain, obs = build_scene(scene)
+    sm = arm.scene_model()
+    orc = Oracle(sm)
+    M = 10071 if scene == "c5m" else 1500
+    q = sample_q(chain, M, seed=41)
+    d, w, rows = arm.proximity_jacobians(q)
+    dr, wr, rr = orc.proximity_jacobian(q)
+    assert_bitwise(d, dr, "mesh proximity distances")
+    assert_bitwise(w, wr, "mesh proximity witnesses")
+    assert_bitwise(rows, rr, "mesh proximity jacobian rows")
+    assert rows.shape == (M, sm.n_pairs, chain.dof) and np.abs(rows).max() > 0.1 and (d < 0).any() and (d > 0).any()
+    assert_bitwise(arm.pair_distances(q[:3000]), dr[:3000], "mesh pair distances")
+    dmin, idx = arm.closest_distance(q)
+    dref, iref = orc.closest(q)
+    assert_bitwise(dmin, dref, "mesh closest distance")
+    assert np.array_equal(idx, iref)
+    for thr in (0.0, 0.01):
+        assert np.array_equal(arm.in_collision(q, thr), dmin < thr)
+    # the rows are the gradient of the signed distance where the contact is regular: finite differences on separated pairs
+    b = 7
+    eps = 1e-6
+    for j in range(chain.dof):
+        qp, qm = q[b].copy(), q[b].copy()
+        qp[j] += eps
+        qm[j] -= eps
+        fd = (orc.pair_distances(qp[None])[0] - orc.pair_distances(qm[None])[0]) / (2 * eps)
+        sel = dr[b] > 0.02
+        assert sel.sum() > 10 and np.abs(fd[sel] - rr[b][sel, j]).max() < 5e-4
+    # scalar API: Proximity records against a mesh obstacle
+    prox = arm.distance_to(q[0], obs[0])
+    assert len(prox) >= 10 and all(p.target is obs[0] for p in prox)
+    best = arm.closest_to(q[0])
+    assert best.distance == dref[0]
+
+
+def test_mesh_edges_and_iris_steps(fresh_world, torch_cuda):
+    from numbotics_amd.planning import collision_mask, counter_example_bisection
+    arm, chain, obs = build_scene("c5m")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    q = sample_q(chain, 4000, seed=8)
+    s_, g_ = q[:600], q[600:1200]
+    keep = np.linalg.norm(g_ - s_, axis=1) <= np.pi
+    s_, g_ = s_[keep], g_[keep]
+    for mode in ("connect", "steer"):
+        ok, end, ns = dev.edge_validity(s_, g_, 0.02, 1.5, mode=mode)
+        okr, endr, nsr = orc.edge_validity(s_, g_, 0.02, 1.5, mode=mode, nthreads=8)
+        assert np.array_equal(ok, okr) and np.array_equal(ns, nsr) and 0 < ok.sum() < ok.size
+        assert_bitwise(end, endr, "mesh edge ends")
+    pts = sample_q(chain, 10071, seed=31)
+    mask = collision_mask(arm, pts, 1e-6)
+    assert np.array_equal(mask, orc.validity(pts, 1e-6, nthreads=8)) and mask.any()
+    seed_q = np.zeros(7)
+    assert not arm.in_collision(seed_q, 1e-6)
+    hi = counter_example_bisection(arm, seed_q, pts[mask][:500], 15, 1e-6)
+    assert np.asarray(arm.in_collision(hi, 1e-6)).all()
+
+
+@pytest.mark.parametrize("seed", [201, 203, 204, 207, 208, 211])
+def test_random_mechanisms_with_mesh_links_among_mesh_obstacles(fresh_world, seed, torch_cuda, tmp_path):
+    """Fuzz: random trees whose links carry primitives AND meshes (scaled, some files with two objects) among random
+    obstacles of every kind incl. Mesh bodies with mesh_scale / offset / auto_center / collision_margin and planes."""
+    import os
+    from numbotics_amd.physics import GraphChain
+    from numbotics_amd.robots import Arm
+    from random_scenes import random_urdf, random_obstacles
+    rng = np.random.default_rng(seed)
+    chain = GraphChain.from_urdf(random_urdf(rng, int(rng.integers(4, 10)), str(tmp_path / "fuzz.urdf"), meshes=True))
+    if chain.dof == 0:
+        pytest.skip("all joints fixed")
+    arm = Arm(chain)
+    obs = random_obstacles(rng, int(rng.integers(2, 7)), mesh_dir=str(tmp_path))
+    sm = arm.scene_model()
+    if sm.n_pairs == 0 or sm.n_hulls == 0:
+        pytest.skip("no pairs / no hulls")
+    orc = Oracle(sm)
+    lim = np.asarray(chain.joint_limits, dtype=np.float64)
+    lim = np.where(np.isfinite(lim), lim, np.sign(lim) * np.pi)
+    q = rng.uniform(lim[:, 0], lim[:, 1], (9000, chain.dof))
+    for thr in (0.0, float(rng.choice([0.02, -0.003]))):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref), f"two-kernel path, thr {thr}"
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), f"fused path, thr {thr}"
+        os.environ["NBK_NO_REG_BROAD"] = "1"
+        try:
+            assert np.array_equal(arm.in_collision(q, thr), ref), f"LDS broadphase, thr {thr}"
+        finally:
+            del os.environ["NBK_NO_REG_BROAD"]
+    d, w, rows = arm.proximity_jacobians(q[:600])
+    dr, wr, rr = orc.proximity_jacobian(q[:600])
+    assert_bitwise(d, dr, "fuzz distances")
+    assert_bitwise(w, wr, "fuzz witnesses")
+    assert_bitwise(rows, rr, "fuzz jacobian rows")
+    dmin, idx = arm.closest_distance(q[:1500])
+    dref, iref = orc.closest(q[:1500])
+    assert_bitwise(dmin, dref, "fuzz closest")
+    assert np.array_equal(idx, iref)
+    _, dev = arm._scene_device()
+    ok, end, ns = dev.edge_validity(q[:150], q[150:300], 0.03, 1.5)
+    okr, endr, nsr = orc.edge_validity(q[:150], q[150:300], 0.03, 1.5)
+    assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
+    assert len(obs) >= 2
+
+
+def test_hull_descriptor_errors_at_the_c_boundary(fresh_world, torch_cuda):
+    """A hull index outside the table, an empty hull or missing tables are NBK_ERR_INVALID, not a fault."""
+    import ctypes as C
+    from numbotics_amd import _lib
+    from numbotics_amd.engine import DeviceModel
+    arm, chain, obs = build_scene("c2m")
+    sm = arm.scene_model()
+    DeviceModel(sm)                                             # the good descriptor builds
+    import copy
+    bad = copy.copy(sm)
+    bad.rshape_param = sm.rshape_param.copy()
+    bad.rshape_param[np.flatnonzero(sm.rshape_type == 5)[0], 0] = sm.n_hulls          # one past the end
+    with pytest.raises(_lib.NbkError):
+        DeviceModel(bad)
+    bad = copy.copy(sm)
+    bad.hull_vert_begin = sm.hull_vert_begin.copy()
+    bad.hull_vert_begin[1] = bad.hull_vert_begin[0]                                      # a hull without vertices
+    with pytest.raises(_lib.NbkError):
+        DeviceModel(bad)
+    assert _lib.load().nbk_abi_version() == 2

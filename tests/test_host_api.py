@@ -18,7 +18,7 @@ def test_capi_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.nbk_abi_version() == 1
+    assert lib.nbk_abi_version() == 2
     assert lib.nbk_status_string(-2).decode() == "no HIP device available"
     assert lib.nbk_device_count() >= 0
 
