@@ -11,7 +11,16 @@
  *   - plain pointers and sizes, no torch types; every array pointer that is not marked "host" is a
  *     DEVICE pointer (hipMalloc / torch.cuda tensor.data_ptr()) on the current device;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous
- *     with respect to the host and capturable into a hipGraph (no allocation, no synchronisation);
+ *     with respect to the host and capturable into a hipGraph (no allocation, no synchronisation).
+ *     Two qualifications, both about the library's own scratch memory: nbk_validity_batch and
+ *     nbk_edge_validity_batch keep one scratch set per (descriptor, stream), allocated on that
+ *     stream's FIRST call (and regrown when a later batch needs more): such a call allocates and may
+ *     wait for that stream's earlier work.  Captured before the scratch exists they return
+ *     NBK_ERR_UNSUPPORTED (run the call once outside the capture, or use nbk_validity_batch_ws, whose
+ *     scratch is the caller's); captured after, they are self-contained graph nodes.  The *_host
+ *     conveniences synchronise by definition;
+ *   - every compute call must be made with the descriptor's device current (hipSetDevice):
+ *     NBK_ERR_INVALID otherwise;
  *   - float64 everywhere (the reference computes in float64); q is row-major (B, n_q);
  *   - return value: NBK_OK or a negative status; no exceptions cross the boundary;
  *   - a descriptor is immutable after creation and may be shared by streams and threads.
@@ -164,8 +173,9 @@ int32_t nbk_validity_batch(const nbk_model *m, const double *q, int64_t B, doubl
  * no workspace runs the slower fused single-kernel path).  The queue is sized
  * for the worst case (every pair of every configuration of a tile survives): up to 1 GiB, up to 8 GiB for descriptors with
  * more than 512 pairs; larger batches are processed in tiles of that size.
- * nbk_validity_batch itself keeps one internal workspace per descriptor (grown with hipMalloc on demand,
- * calls on the same descriptor serialise on it): use this variant for concurrent streams or graph capture.
+ * nbk_validity_batch itself keeps one internal workspace per (descriptor, stream), grown with hipMalloc on demand: calls on
+ * different streams share nothing and overlap; use this variant when the memory must be the caller's (allocator pools,
+ * graphs that outlive a regrowth of the internal scratch).
  */
 int64_t nbk_validity_workspace_bytes(const nbk_model *m, int64_t B);
 int32_t nbk_validity_batch_ws(const nbk_model *m, const double *q, int64_t B, double threshold,
@@ -208,6 +218,11 @@ int32_t nbk_proximity_jacobian_batch(const nbk_model *m, const double *q, int64_
  *   0 also for d <= float32 eps (the reference returns None);
  *   end (optional) [E][n_q]: goal (connect) or traj(T_f) (steer), NaN for the degenerate edge;
  *   n_samples (optional) [E] int32 = len(T).
+ * Asynchronous: the sample count is only known on the device, so the launches cover the CAPACITY of the stream's edge scratch
+ * (at least E * (ceil(max_distance / resolution) + 2) samples, and 1.25 x what the previous call on the stream needed, which
+ * the device reports through pinned memory) and blocks beyond the true count exit at once; edges that do not fit are walked
+ * by one wave each -- same results.  (Robots whose primitives exceed the LDS-parked layout -- some 30+ -- size the scratch
+ * with one read-back instead and cannot be captured.)
  */
 int32_t nbk_edge_validity_batch(const nbk_model *m, const double *starts, const double *goals,
                                 const double *dist, int64_t E, double resolution, double max_distance,
@@ -228,6 +243,18 @@ int32_t nbk_knn_prefix(const float *points, int32_t n_points, int32_t dim, int32
  * the kernels use (all arrays device, length n). */
 int32_t nbk_selftest_math(const double *a, const double *b, int64_t n, double *sin_out, double *cos_out,
                           double *sqrt_out, double *div_out, void *stream);
+
+/*
+ * The reference's scalar contracts from HOST memory, latency-optimised: Arm.in_collision(q) on one configuration
+ * (numbotics/robots/arm.py:603-604) and DiscreteConnector.connect / steer on one edge (connectors.py:57-100), as the
+ * sequential planners call them (numbotics/planning/sampling_based/planners/prm.py:40, rrt.py:36).  Inputs and results go through pinned,
+ * device-mapped memory owned by the descriptor (no staging copies), on a private stream; the call returns when the result
+ * is there.  q / start / goal / end: host [n_q].  dist < 0 = Euclidean norm.  Calls on one descriptor serialise.
+ */
+int32_t nbk_validity_scalar_host(const nbk_model *m, const double *q, double threshold, int32_t *in_collision);
+int32_t nbk_edge_validity_scalar_host(const nbk_model *m, const double *start, const double *goal, double dist,
+                                      double resolution, double max_distance, int32_t mode, double threshold,
+                                      int32_t *valid, double *end, int32_t *n_samples);
 
 /* Host-buffer conveniences for callers without a device allocator (PCIe inclusive; they allocate,
  * copy, run, copy back and synchronise). */

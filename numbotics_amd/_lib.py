@@ -22,6 +22,7 @@ SYMBOLS = [
     "nbk_validity_batch_ws", "nbk_closest_batch",
     "nbk_pair_distances_batch", "nbk_proximity_jacobian_batch", "nbk_edge_validity_batch", "nbk_selftest_math",
     "nbk_fk_batch_host", "nbk_validity_batch_host", "nbk_knn_prefix",
+    "nbk_validity_scalar_host", "nbk_edge_validity_scalar_host",
 ]
 
 
@@ -88,8 +89,35 @@ def load():
     lib.nbk_fk_batch_host.argtypes = [vp, vp, i64, vp, i32, vp, vp]
     lib.nbk_validity_batch_host.argtypes = [vp, vp, i64, f64, vp]
     lib.nbk_model_num_pairs.argtypes = [vp]
+    lib.nbk_validity_scalar_host.argtypes = [vp, vp, f64, vp]
+    lib.nbk_edge_validity_scalar_host.argtypes = [vp, vp, vp, f64, f64, f64, i32, f64, vp, vp, vp]
+    lib.nbk_debug_set_option.argtypes = [C.c_char_p, i64]
     _lib = lib
     return lib
+
+
+# tuning / diagnostic switches of the library (process-wide; seeded once from the NBK_* environment variables when the library
+# is loaded, never read again): name -> default.  None of them changes a result.
+DEBUG_OPTIONS = {"two_kernel_min_b": 1, "edge_batch_min_e": 1, "no_reg_broad": 0, "f64_broad": 0, "jac_two_sweep": 0,
+                 "closest_brute": 0}
+
+
+def set_debug_option(name: str, value: int):
+    check(load().nbk_debug_set_option(name.encode(), int(value)), f"nbk_debug_set_option({name})")
+
+
+class debug_option:
+    """``with debug_option("two_kernel_min_b", 10**9): ...`` -- route calls through another kernel path (tests, tools)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        set_debug_option(self.name, self.value)
+
+    def __exit__(self, *exc):
+        set_debug_option(self.name, DEBUG_OPTIONS[self.name])
+        return False
 
 
 def check(status: int, what: str):

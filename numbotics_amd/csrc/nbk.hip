@@ -74,10 +74,16 @@ struct DevModel {
     int bq_count[4];              // pairs per broadphase category
     const int* bq_tab;            // [P][4] broadphase order (category-major): centre row of A (3*shape), centre row of B or world index,
                                   //        index into the vp_* tables, category (0 plane, 1 robot-robot, 2 robot-world, 3 robot-world box)
-    int dbg;                              // ablation switches for profiling runs (NBK_ABLATE env): 1 = no narrowphase, 2 = no pair loop,
-                                          // 4 = no queue appends, 8 = no GJK phase, 16 = no FK replay, 32 = no cores, 64 = no pre-check,
-                                          // 128 = k_narrow accumulates per-phase cycle counts (tools/narrow_prof.py)
+    int dbg;                              // ablation switches, ONLY in builds made with -DNBK_ABLATE_BUILD (tools/ablate.py, tools/narrow_prof.py;
+                                          // the product library compiles them out: NBK_DBG is the constant 0): 1 = no narrowphase, 2 = no pair
+                                          // loop, 4 = no queue appends, 8 = no GJK phase, 16 = no FK replay, 32 = no cores, 64 = no pre-check,
+                                          // 128 = k_narrow accumulates per-phase cycle counts
 };
+#ifdef NBK_ABLATE_BUILD
+#define NBK_DBG(m) ((m).dbg)
+#else
+#define NBK_DBG(m) 0
+#endif
 
 }  // namespace nbk
 
@@ -88,7 +94,34 @@ struct EdgeSrc {
     const double* starts;
     const double* goals;
     const double* plan;                  // [E][3] step, T_f, n (as double)
-    const unsigned long long* map;       // [total] or nullptr = plain q rows
+    const unsigned long long* map;       // [capacity] or nullptr = plain q rows
+    const unsigned long long* total;     // edge mode: device address of the sample count (known only on the device: the launch
+                                         // covers the scratch's capacity, blocks beyond the count exit at once)
+    long long b0;                        // first configuration of this tile within the flat batch
+};
+// configurations this launch really has: the tile size B, or what is left of the device-side sample count
+NBK_DEV int64_t effective_batch(const EdgeSrc& es, int64_t B) {
+    if (es.total == nullptr) return B;
+    const long long left = (long long)(*es.total) - es.b0;
+    return left < (long long)B ? (left < 0 ? 0 : (int64_t)left) : B;
+}
+}  // namespace nbk
+
+namespace nbk {
+// per-(descriptor, stream) scratch.  The float32 broadphase tables stay valid while the threshold does not change and the queue
+// counters exist twice -- a call uses set (epoch & 1), its narrowphase clears the other set for the next call -- so steady-state
+// calls launch two kernels, not three.  The edge path keeps plan / counts / offsets / sample map / mask words here, sized for a
+// capacity in samples; `stats` is pinned host memory the device writes the true sample count into (read, never waited for, at the
+// start of the NEXT call to grow the capacity).
+struct StreamWs {
+    hipStream_t stream;
+    std::mutex mu;                  // two host threads driving one stream
+    void* ws; size_t ws_bytes;
+    bool ready; double thr; unsigned epoch;
+    void* ews; size_t ews_bytes;
+    long long ecap_edges; unsigned long long ecap_samples;
+    unsigned long long* stats;      // [4] pinned + mapped: samples needed by the last finished edge call, edges served by the overflow kernel
+    unsigned long long* stats_dev;  // device alias of `stats`
 };
 }  // namespace nbk
 
@@ -107,18 +140,15 @@ struct nbk_model {
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
     bool margins_zero;        // every pair that can reach GJK (no point core, not point/segment x point/segment) has mA = mB = 0:
                               // with threshold 0 its contact threshold tc is exactly 0 and the boolean walk decides it
-    // internal scratch of nbk_validity_batch (queue of broadphase survivors); grown on demand under `mu`
-    void* ws;
-    size_t ws_bytes;
-    // the internal workspace keeps its float32 broadphase tables between calls with the same threshold, and two sets of queue
-    // counters: a call uses set (epoch & 1) and its narrowphase clears the other one for the next call -- no prepare launch
-    bool ws_ready;
-    double ws_thr;
-    unsigned ws_epoch;
-    hipStream_t ws_stream;    // stream of the last call that used the internal workspace: a call on another stream first waits for it
-    void* ews;                // scratch of the batched edge path
-    size_t ews_bytes;
+    // Internal scratch of nbk_validity_batch / nbk_edge_validity_batch: ONE SET PER STREAM (created on a stream's first call), so
+    // calls on different streams share nothing mutable and overlap on the device; `mu` only guards the list itself.
     std::mutex mu;
+    std::vector<nbk::StreamWs*> wss;
+    // nbk_validity_scalar_host: pinned, device-mapped staging for one configuration + its private stream
+    std::mutex scalar_mu;
+    double* scalar_q;         // [n_q] host-pinned, read by the kernel through its device alias
+    unsigned long long* scalar_out;
+    hipStream_t scalar_stream;
 };
 
 namespace nbk {
@@ -952,7 +982,7 @@ NBK_DEV void load_core_any(const DevModel& m, const double* lds_s, int ref, int 
 NBK_DEV void drain_queue(const DevModel& m, const double* lds_s, const unsigned* queue, int qn, unsigned* lds_hit,
                          int lane, double thr) {
     __syncthreads();            // one wave per workgroup: orders the queue / flag writes before the reads below
-    if (m.dbg & 1) qn = 0;
+    if (NBK_DBG(m) & 1) qn = 0;
     for (int base = 0; base < qn; base += WAVE) {
         const int i = base + lane;
         if (i < qn) {
@@ -978,7 +1008,7 @@ NBK_DEV bool wave_collides(const DevModel& m, const double* lds_s, unsigned* lds
     lds_hit[lane] = 0u;
     bool hit = false;
     int qn = 0;                                       // wave-uniform
-    const int np = (m.dbg & 2) ? 0 : m.n_pairs;
+    const int np = (NBK_DBG(m) & 2) ? 0 : m.n_pairs;
     for (int p = 0; p < np; ++p) {
         const int* tab = m.vp_tab + 4 * p;
         const int refA = tab[0], refB = tab[1];
@@ -1143,7 +1173,7 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
     for (int i = t; i < W * 16; i += 256) { wkey[i] = -1.0f; wtc[i] = 0.0f; wp[i] = -1; }
     if (t < 16) rho[t] = t < m.n_rshapes ? (float)m.rs_core[6 * t + 5] * up : 0.0f;
     __syncthreads();
-    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    const int P = (NBK_DBG(m) & 2) ? 0 : m.n_pairs;
     for (int j = t; j < P; j += 256) {
         const int* bt = m.bq_tab + 4 * j;
         const int a = bt[0] / 3, p = bt[2], cat = bt[3];
@@ -1216,7 +1246,7 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
     const int lane = threadIdx.x;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nq = m.n_q;
-    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    const int P = (NBK_DBG(m) & 2) ? 0 : m.n_pairs;
     double* lds_raw = lds;
     const int qrows = (WAVE * nq * 8 >= BQ_CAP * 4) ? nq : (BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
     double* lds_fr = lds_raw + WAVE * qrows;
@@ -1225,7 +1255,9 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
     double* lds_w = lds_pc + 4 * m.n_pairs;
     // the queue reuses the q slab, which is dead once the sweep is over (host sizes the region for both)
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
-    const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
+    const int64_t Beff = effective_batch(es, B);
+    if (base >= Beff) return;               // edge mode: the launch covers the scratch's capacity, this block lies beyond the samples
+    const int rows_i = (int)((Beff - base) < WAVE ? (Beff - base) : WAVE);
     // ---- stage q (coalesced), no transposed copy: lane reads lds_raw[lane*nq + j] -------------------------
     if (es.map != nullptr) {
         // edge mode: this lane's configuration is an interpolation sample
@@ -1319,7 +1351,7 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
     int qn = 0;
     int j0 = 0;
     for (int cat = 0; cat < 4; ++cat) {
-        const int ncat = (m.dbg & 2) ? 0 : m.bq_count[cat];
+        const int ncat = (NBK_DBG(m) & 2) ? 0 : m.bq_count[cat];
         for (int c0 = 0; c0 < ncat; c0 += WAVE) {
             const int nn = (ncat - c0) < WAVE ? (ncat - c0) : WAVE;
             const double* pc0 = lds_pc + 4 * (j0 + c0);
@@ -1374,7 +1406,7 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
                     bits |= !((dot3(d, n) - rhoA) >= key) ? (1ull << u) : 0ull;
                 }
             }
-            if (!active || hit || (m.dbg & 4)) bits = 0ull;
+            if (!active || hit || (NBK_DBG(m) & 4)) bits = 0ull;
             enqueue_bits(m, bits, j0 + c0, lds_pc, lds_queue, qn, lane, base, q_count, q_items, cap);
         }
         j0 += ncat;
@@ -1410,7 +1442,9 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
     int* lds_rp = reinterpret_cast<int*>(lds_wtc + W * S);       // [S*S] sorted pair index of the slot
     int* lds_wp = lds_rp + S * S;                                // [W*S]
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
-    const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
+    const int64_t Beff = effective_batch(es, B);
+    if (base >= Beff) return;               // edge mode: the launch covers the scratch's capacity, this block lies beyond the samples
+    const int rows_i = (int)((Beff - base) < WAVE ? (Beff - base) : WAVE);
     // ---- stage q ------------------------------------------------------------------------------------------------------
     if (es.map != nullptr) {
         if (lane < rows_i) {
@@ -1439,7 +1473,7 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
     for (int i = lane; i < S * S; i += WAVE) { lds_rkey[i] = -1.0; lds_rp[i] = -1; }
     for (int i = lane; i < W * S; i += WAVE) { lds_wkey[i] = -1.0; lds_wtc[i] = 0.0; lds_wp[i] = -1; }
     __syncthreads();
-    const int P = (m.dbg & 2) ? 0 : m.n_pairs;
+    const int P = (NBK_DBG(m) & 2) ? 0 : m.n_pairs;
     for (int j = lane; j < P; j += WAVE) {
         const int* t = m.bq_tab + 4 * j;
         const int a = t[0] / 3, p = t[2], cat = t[3];
@@ -1587,7 +1621,7 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
                 }
             }
         }
-        if (!active || hit || (m.dbg & 4)) bits = 0ull;
+        if (!active || hit || (NBK_DBG(m) & 4)) bits = 0ull;
         while (true) {
             const bool has = bits != 0ull;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
@@ -1681,7 +1715,9 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     const int* tab_wp = reinterpret_cast<const int*>(tab_wtc + (size_t)W * 16);
     const float* tab_rho = reinterpret_cast<const float*>(tab_wp + (size_t)W * 16);
     const float up = 1.0f + 2.4e-7f;
-    const int rows_i = (int)((B - base) < WAVE ? (B - base) : WAVE);
+    const int64_t Beff = effective_batch(es, B);
+    if (base >= Beff) return;               // edge mode: the launch covers the scratch's capacity, this block lies beyond the samples
+    const int rows_i = (int)((Beff - base) < WAVE ? (Beff - base) : WAVE);
     if (es.map != nullptr) {
         if (lane < rows_i) {
             unsigned e;
@@ -1852,7 +1888,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 }
             }
         }
-        if (!active || hit || (m.dbg & 4)) bits = 0ull;
+        if (!active || hit || (NBK_DBG(m) & 4)) bits = 0ull;
         while (true) {
             const bool has = bits != 0ull;
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
@@ -1937,7 +1973,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     // The kernel is latency-bound, so dependent global round trips are kept to three: {count, first item} ->
     // {pair record, q row} -> shape constants.  The first chunk's item is loaded before the count is known (the slot
     // is inside the allocated sub-queue either way; its value is used only when the slot is below the count).
-    const bool prof = (m.dbg & 128) != 0;
+    const bool prof = (NBK_DBG(m) & 128) != 0;
     unsigned long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     NBK_STAMP(0);
     q_items += (unsigned long long)sub * cap;
@@ -1946,7 +1982,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     if (i_first < cap) item_first = __hip_atomic_load(q_items + i_first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned long long n = __hip_atomic_load(q_count + sub * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > cap) n = cap;
-    if (m.dbg & 1) n = 0;
+    if (NBK_DBG(m) & 1) n = 0;
     for (unsigned long long i0 = (unsigned long long)part * NARROW_T; i0 < n; i0 += (unsigned long long)nparts * NARROW_T) {
         // ---- phase 1 -----------------------------------------------------------------------------------------------
         {
@@ -1996,7 +2032,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 }
             }
             NBK_STAMP(2);
-            for (int k = 0; k < ((m.dbg & 16) ? 0 : m.n_joints); ++k) {
+            for (int k = 0; k < ((NBK_DBG(m) & 16) ? 0 : m.n_joints); ++k) {
                 const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
                 if (__builtin_amdgcn_ballot_w64(in_a || in_b) == 0ull) continue;
                 if (in_a || in_b) {
@@ -2015,14 +2051,14 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
 #pragma unroll
             for (int e = 0; e < 3; ++e) { A.c[e] = 0.0; Bc.c[e] = 1.0; A.h[e] = 0.0; Bc.h[e] = 0.0; A.ax[0][e] = A.ax[1][e] = A.ax[2][e] = 0.0; Bc.ax[0][e] = Bc.ax[1][e] = Bc.ax[2][e] = 0.0; }
             A.rad = Bc.rad = A.margin = Bc.margin = A.rho = Bc.rho = 0.0;
-            if (live && !(m.dbg & 32)) {
+            if (live && !(NBK_DBG(m) & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
                 if (prof) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; if (acc == 12345.678) mark_hit(b, mask_bits, mask_bytes); }
                 NBK_STAMP(4);
                 const double* cst = m.vp_cst + 4 * p;
                 int verdict;
-                if (m.dbg & 64) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[1][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[1][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; verdict = (acc == 12345.678) ? 1 : 0; }
+                if (NBK_DBG(m) & 64) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[1][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[1][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; verdict = (acc == 12345.678) ? 1 : 0; }
                 else if (Bc.kind == K_PLANE) verdict = plane_collides(A, Bc, thr, cst[2]) ? 1 : 0;
                 else {
                     // step 2 of the predicate in float64: the float32 broadphase only culled what is certainly free
@@ -2039,7 +2075,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             NBK_STAMP(5);
             // ---- phase 2: the undecided lanes walk GJK on their own item, one iteration per trip ---------------------------
             // (a chunk has at most 64 undecided items and 64 lanes: nothing to redistribute, so no pool)
-            bool have = pooled && !(m.dbg & 8);
+            bool have = pooled && !(NBK_DBG(m) & 8);
             if constexpr (MODE == 1) {
                 GjkBool gb;
                 gjkb_init(gb, A, Bc);
@@ -2082,55 +2118,6 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 atomicMax(&g_narrow_prof[12], stamp[6]);
             }
         }
-    }
-}
-
-// experiment (NBK_SORT_ITEMS): sorts every sub-queue by (pair, configuration) so that the chunks k_narrow takes are
-// pair-homogeneous; one workgroup per sub-queue, up to 4096 items in LDS, bitonic
-__global__ __launch_bounds__(256) void k_sort_items(DevModel m, int mode, unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
-                                                     unsigned long long cap) {
-    __shared__ unsigned long long key[4096];
-    const unsigned sub = blockIdx.x;
-    unsigned long long n = q_count[sub * CNT_STRIDE];
-    if (n > cap) n = cap;
-    if (n > 4096ull) n = 4096ull;
-    unsigned long long* it = q_items + (unsigned long long)sub * cap;
-    for (int i = threadIdx.x; i < 4096; i += 256) {
-        unsigned long long v = ~0ull;
-        if ((unsigned long long)i < n) {
-            const unsigned long long x = it[i];
-            const unsigned long long p = x & 0xFFFFFull, cfg = x >> 20;
-            if (mode == 1) v = (p << 44) | cfg;                       // pair-major
-            else {
-                // coarse classes, pairs mixed inside a class: 2 = joints to replay (depth of the deeper shape, in twos),
-                // 3 = kind pair, 4 = both
-                const int4 info = m.vp_info[(int)p];
-                const unsigned mk = (unsigned)info.z | (unsigned)info.w;
-                const unsigned depth = mk ? 32u - (unsigned)__builtin_clz(mk) : 0u;
-                const unsigned ka = info.x >= 0 ? (unsigned)m.rs_kind[info.x] : (unsigned)m.ws_kind[~info.x];
-                const unsigned kb = info.y >= 0 ? (unsigned)m.rs_kind[info.y] : (unsigned)m.ws_kind[~info.y];
-                const unsigned long long cls = mode == 2 ? (depth / 2) : (mode == 3 ? (ka * 8 + kb) : ((depth / 2) * 64 + ka * 8 + kb));
-                v = (cls << 54) | ((cfg & 0x3FFFFFFFFull) << 20) | p;
-            }
-        }
-        key[i] = v;
-    }
-    __syncthreads();
-    for (int k = 2; k <= 4096; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < 4096; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = (i & k) == 0;
-                    const unsigned long long a = key[i], b = key[l];
-                    if ((a > b) == up) { key[i] = b; key[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; (unsigned long long)i < n; i += 256) {
-        const unsigned long long v = key[i];
-        it[i] = mode == 1 ? (((v & 0xFFFFFFFFFFFull) << 20) | (v >> 44)) : ((((v >> 20) & 0x3FFFFFFFFull) << 20) | (v & 0xFFFFFull));
     }
 }
 
@@ -2414,10 +2401,16 @@ __global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __rest
 __global__ __launch_bounds__(64) void k_edges(DevModel m, const double* __restrict__ starts, const double* __restrict__ goals,
                                                const double* __restrict__ dist, int64_t E, double resolution,
                                                double max_distance, int mode, double thr, uint8_t* __restrict__ valid,
-                                               double* __restrict__ end, int32_t* __restrict__ n_samples) {
+                                               double* __restrict__ end, int32_t* __restrict__ n_samples,
+                                               const uint8_t* __restrict__ only, unsigned long long* __restrict__ stats) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int64_t e = blockIdx.x;
+    // `only`: serve just the edges the flat batch could not hold (k_edge_expand's overflow marks)
+    if (only != nullptr) {
+        if (!only[e]) return;
+        if (lane == 0 && stats != nullptr) atomicAdd(stats + 1, 1ull);
+    }
     const int nq = m.n_q;
     double* lds_q = lds;
     double* lds_s = lds_q + WAVE * nq;
@@ -2542,15 +2535,25 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
     for (int64_t i = lo; i < hi; ++i) { offs[i] = run; run += cnt[i]; }
 }
 
-__global__ __launch_bounds__(64) void k_edge_expand(const unsigned long long* __restrict__ offs, int64_t E, unsigned long long* __restrict__ map) {
+// sample map of the flat batch; an edge that does not fit the scratch's capacity completely is marked (ovf) and left to the
+// one-wave-per-edge kernel
+__global__ __launch_bounds__(64) void k_edge_expand(const unsigned long long* __restrict__ offs, int64_t E, unsigned long long* __restrict__ map,
+                                                     unsigned long long cap, uint8_t* __restrict__ ovf) {
     const int64_t e = blockIdx.x;
-    const unsigned long long o = offs[e], n = offs[e + 1] - o;
+    const unsigned long long o = offs[e], hi = offs[e + 1];
+    const bool over = hi > cap;
+    if (threadIdx.x == 0) ovf[e] = over ? 1 : 0;
+    const unsigned long long n = (hi < cap ? hi : cap) - (o < cap ? o : cap);
     for (unsigned long long i = threadIdx.x; i < n; i += WAVE) map[o + i] = ((unsigned long long)e << 32) | i;
 }
 
 __global__ __launch_bounds__(64) void k_edge_reduce(const unsigned long long* __restrict__ offs, int64_t E, const uint64_t* __restrict__ words,
-                                                     uint8_t* __restrict__ valid) {
+                                                     const uint8_t* __restrict__ ovf, uint8_t* __restrict__ valid,
+                                                     unsigned long long* __restrict__ stats) {
     const int64_t e = blockIdx.x;
+    // the sample count this call needed goes to pinned host memory: the next call sizes its scratch from it
+    if (e == 0 && threadIdx.x == 0 && stats != nullptr) { stats[0] = offs[E]; stats[1] = 0ull; }
+    if (ovf[e]) return;                      // walked by k_edges
     const unsigned long long o = offs[e], n = offs[e + 1] - o;
     bool hit = false;
     for (unsigned long long i = threadIdx.x; i < n; i += WAVE) {
@@ -3033,10 +3036,13 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.bq_static = reinterpret_cast<const double*>(base + o.bs);
     for (int c = 0; c < 4; ++c) { m.bq_count[c] = 0; }
     for (int i = 0; i < P; ++i) m.bq_count[bq_tab[4 * i + 3]]++;
+#ifdef NBK_ABLATE_BUILD
     { const char* ab = getenv("NBK_ABLATE"); m.dbg = ab ? atoi(ab) : 0; }
+#else
+    m.dbg = 0;
+#endif
     M->blob = dev;
-    M->ws = nullptr; M->ws_bytes = 0; M->ws_ready = false; M->ws_thr = 0.0; M->ws_epoch = 0; M->ws_stream = nullptr;
-    M->ews = nullptr; M->ews_bytes = 0;
+    M->scalar_q = nullptr; M->scalar_out = nullptr; M->scalar_stream = nullptr;
     M->blob_bytes = B.bytes.size();
     M->n_pairs = P; M->n_q = d->n_q; M->n_joints = J;
     M->h_joint_qidx.assign(d->joint_qidx, d->joint_qidx + J);
@@ -3054,8 +3060,15 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
 void nbk_model_destroy(nbk_model* m) {
     if (m == nullptr) return;
     if (m->blob) (void)hipFree(m->blob);
-    if (m->ws) (void)hipFree(m->ws);
-    if (m->ews) (void)hipFree(m->ews);
+    for (StreamWs* w : m->wss) {
+        if (w->ws) (void)hipFree(w->ws);
+        if (w->ews) (void)hipFree(w->ews);
+        if (w->stats) (void)hipHostFree(w->stats);
+        delete w;
+    }
+    if (m->scalar_q) (void)hipHostFree(m->scalar_q);
+    if (m->scalar_out) (void)hipHostFree(m->scalar_out);
+    if (m->scalar_stream) (void)hipStreamDestroy(m->scalar_stream);
     delete m;
 }
 
@@ -3086,11 +3099,54 @@ static int make_path(const nbk_model* m, const int32_t* path, int32_t path_len, 
     return NBK_OK;
 }
 
+// ---- tuning / diagnostic switches: process-wide, seeded ONCE from the environment when the library is loaded -------
+// (no getenv on any call path).  nbk_debug_set_option changes them at run time (tests, tools); none of them changes a result.
+struct Options {
+    long long two_kernel_min_b;     // NBK_TWO_KERNEL_MIN_B: batches below this size run the fused kernel k_validity.  The broadphase +
+                                    // narrowphase pair measured faster at every size (0.040 vs 0.050 ms for 64 configurations), so: 1
+    long long edge_batch_min_e;     // NBK_EDGE_BATCH_MIN_E: edge batches below this size run one wave per edge (k_edges); default 1
+    long long no_reg_broad;         // NBK_NO_REG_BROAD: the LDS broadphase k_broad instead of the register broadphases
+    long long f64_broad;            // NBK_F64_BROAD: the float64 register broadphase instead of the conservative float32 one
+    long long jac_two_sweep;        // NBK_JAC_TWO_SWEEP: the general Jacobian kernel also for short paths
+    long long closest_brute;        // NBK_CLOSEST_BRUTE: every pair instead of branch-and-bound
+};
+static long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
+static Options g_opt = {env_ll("NBK_TWO_KERNEL_MIN_B", 1), env_ll("NBK_EDGE_BATCH_MIN_E", 1), env_ll("NBK_NO_REG_BROAD", 0),
+                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0)};
+
+// diagnostic (not part of include/nbk.h): set one of the switches above by name; returns NBK_ERR_INVALID for an unknown name
+extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
+    if (name == nullptr) return NBK_ERR_INVALID;
+    struct { const char* n; long long* v; } tab[] = {
+        {"two_kernel_min_b", &g_opt.two_kernel_min_b}, {"edge_batch_min_e", &g_opt.edge_batch_min_e}, {"no_reg_broad", &g_opt.no_reg_broad},
+        {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute}};
+    for (auto& t : tab) if (strcmp(t.n, name) == 0) { *t.v = (long long)value; return NBK_OK; }
+    return NBK_ERR_INVALID;
+}
+
+// every compute entry point: the descriptor's memory lives on the device it was created on
+static int32_t check_device(const nbk_model* m) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != m->device) {
+        snprintf(g_err, sizeof(g_err), "descriptor belongs to device %d, the current device is %d", m->device, dev);
+        return NBK_ERR_INVALID;
+    }
+    return NBK_OK;
+}
+#define NBK_DEVICE(m) do { const int32_t d_ = check_device(m); if (d_ != NBK_OK) return d_; } while (0)
+
+static bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
+
 static inline unsigned blocks_for(int64_t B) { return (unsigned)((B + WAVE - 1) / WAVE); }
 
 int32_t nbk_fk_batch(const nbk_model* m, const double* q, int64_t B, const int32_t* path, int32_t path_len,
                      const double* local, const double* local_pose, double* T_out, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || T_out == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     PathArg pa;
     const int st = make_path(m, path, path_len, local, pa);
     if (st != NBK_OK) return st;
@@ -3148,6 +3204,7 @@ void nbk_frameset_destroy(nbk_frameset* fs) {
 
 int32_t nbk_fk_frames_batch(const nbk_model* m, const nbk_frameset* fs, const double* q, int64_t B, double* T_out, void* stream) {
     if (m == nullptr || fs == nullptr || B < 0 || (B > 0 && (q == nullptr || T_out == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (B == 0) return NBK_OK;
     const size_t tr = (size_t)(m->n_q > 17 ? m->n_q : 17);
     const size_t lds = sizeof(double) * WAVE * ((size_t)m->n_q + 12 * (size_t)m->d.frame_slots + tr);
@@ -3169,13 +3226,13 @@ int32_t nbk_knn_prefix(const float* points, int32_t n_points, int32_t dim, int32
 int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const int32_t* path, int32_t path_len,
                            const double* local, int32_t mode, const double* pose, double* J_out, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || J_out == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (mode < 0 || mode > 2 || (mode != 0 && pose == nullptr && B > 0)) return NBK_ERR_INVALID;
     PathArg pa;
     const int st = make_path(m, path, path_len, local, pa);
     if (st != NBK_OK) return st;
     if (B == 0) return NBK_OK;
-    static const bool two_sweep = getenv("NBK_JAC_TWO_SWEEP") != nullptr;
-    if (pa.len <= 8 && !two_sweep) {
+    if (pa.len <= 8 && !g_opt.jac_two_sweep) {
         const int stride = (6 * m->n_q) | 1;
         const size_t lds_q = (size_t)WAVE * (size_t)m->n_q, lds_rows = (size_t)JAC_ROWS * (size_t)stride;     // the rows reuse the q area
         const size_t lds = sizeof(double) * (lds_q > lds_rows ? lds_q : lds_rows);
@@ -3196,6 +3253,7 @@ int32_t nbk_ik_batch(const nbk_model* m, const double* pose, const double* q0, i
                      const double* local, const double* limits, double tol, int32_t max_iter, int32_t max_failures,
                      double* q_out, uint8_t* success, double* diff_norm, int32_t* iters, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (pose == nullptr || q0 == nullptr || q_out == nullptr || success == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (max_iter < 1 || max_failures < 0 || !(tol >= 0.0)) return NBK_ERR_INVALID;
     PathArg pa;
     const int st = make_path(m, path, path_len, local, pa);
@@ -3219,13 +3277,9 @@ static inline size_t collide_lds(const nbk_model* m) {
 }
 
 // ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
-// batches below this size run the fused kernel k_validity.  The broadphase + narrowphase pair measured faster at every
-// size (0.040 vs 0.050 ms for 64 configurations, 0.053 vs 0.062 ms for 4 096), so the default is 1; NBK_TWO_KERNEL_MIN_B
-// brings the fused kernel back (it also serves nbk_validity_batch_ws calls made without a workspace)
-static inline int64_t two_kernel_min_b() { const char* e = getenv("NBK_TWO_KERNEL_MIN_B"); return e ? atoll(e) : 1; }
 static const size_t WS_MAX_BYTES = size_t(1) << 30;
 static const size_t WS_COUNTER_SET = NSUB * CNT_STRIDE * 8;    // NSUB counters, one cache line each
-static const size_t WS_COUNTERS = 2 * WS_COUNTER_SET;          // two sets (see nbk_model::ws_epoch)
+static const size_t WS_COUNTERS = 2 * WS_COUNTER_SET;          // two sets (see StreamWs::epoch)
 static inline size_t ws_header(const nbk_model* m) {           // counters | per-call float32 broadphase tables
     return (WS_COUNTERS + 4 * (2 * 256 + 3 * (size_t)m->d.n_wshapes * 16 + 16) + 255) & ~size_t(255);
 }
@@ -3270,70 +3324,81 @@ static inline size_t broad_reg_lds(const nbk_model* m, int S) {
     return sizeof(double) * (WAVE * (qrows + 12 * (size_t)m->d.frame_slots) + (size_t)S * S + 2 * W * S) + sizeof(int) * ((size_t)S * S + W * S) + 16;
 }
 
-// broadphase + narrowphase over B configurations (plain q rows, or the samples described by `es`), tiled so
-// that the worst-case queue fits the workspace
-static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
-                                      uint8_t* mask_bytes, void* workspace, hipStream_t st, bool internal);
+// the scratch set of (descriptor, stream); created on the stream's first call.  nullptr: too many streams (use the _ws variant)
+static StreamWs* stream_ws(nbk_model* mm, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(mm->mu);
+    for (StreamWs* w : mm->wss) if (w->stream == st) return w;
+    if (mm->wss.size() >= 64) return nullptr;
+    StreamWs* w = new StreamWs();
+    w->stream = st; w->ws = nullptr; w->ws_bytes = 0; w->ready = false; w->thr = 0.0; w->epoch = 0;
+    w->ews = nullptr; w->ews_bytes = 0; w->ecap_edges = 0; w->ecap_samples = 0; w->stats = nullptr; w->stats_dev = nullptr;
+    mm->wss.push_back(w);
+    return w;
+}
 
-// the internal workspace is one per descriptor: work queued on another stream must have drained before this stream reuses it
-static int32_t internal_ws_enter(nbk_model* mm, hipStream_t st) {
-    if (mm->ws != nullptr && mm->ws_stream != st) {
-        NBK_HIP(hipStreamSynchronize(mm->ws_stream));
-        mm->ws_ready = false;
-    }
-    mm->ws_stream = st;
+// (re)allocate a scratch buffer of this stream's set.  Earlier work of THIS stream may still read the old buffer: wait for it
+// (other streams never touch it).  Never called while capturing.
+static int32_t grow_scratch(hipStream_t st, void*& buf, size_t& have, size_t need, const char* what) {
+    if (have >= need) return NBK_OK;
+    if (buf) { NBK_HIP(hipStreamSynchronize(st)); (void)hipFree(buf); buf = nullptr; have = 0; }
+    hipError_t e = hipMalloc(&buf, need);
+    if (e != hipSuccess) { hip_fail(e, what); return NBK_ERR_ALLOC; }
+    have = need;
     return NBK_OK;
 }
 
-// `internal`: the workspace is the descriptor's own (caller holds its mutex) and keeps state between calls
-static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
-                                 uint8_t* mask_bytes, void* workspace, hipStream_t st, bool internal = false) {
-    const int32_t rc = launch_two_kernel_impl(m, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, internal);
-    if (rc != NBK_OK && internal) const_cast<nbk_model*>(m)->ws_ready = false;      // whatever state the queues are in: start over
-    return rc;
-}
-
+// broadphase + narrowphase over B configurations (plain q rows, or the samples described by `es`), tiled so that the worst-case
+// queue fits the workspace.  `iw`: the workspace is this stream's own set and keeps state between calls (tables, counter epoch);
+// nullptr: caller-owned workspace, or a call being captured into a graph -- self-contained: every call prepares its tables
+// and clears its counters itself.
 static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
-                                      uint8_t* mask_bytes, void* workspace, hipStream_t st, bool internal) {
-    nbk_model* mm = const_cast<nbk_model*>(m);
+                                      uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw) {
     unsigned long long* count_set0 = static_cast<unsigned long long*>(workspace);
     unsigned long long* count = count_set0;
     unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_header(m));
+    const bool internal = iw != nullptr;
     const int64_t tile = tile_configs(m, B);
+    // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
+    // distance predicate only, else the build with both
+    bool any_zero = false, any_nonzero = false, any_negative = false;
+    for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
+        const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
+        if (tc == 0.0) any_zero = true; else any_nonzero = true;
+        if (!(tc > 0.0)) any_negative = true;          // (a NaN threshold counts as not positive)
+    }
+    const int S = m->d.n_rshapes;
+    const bool use_reg = S <= 16 && (!g_opt.no_reg_broad || !m->lds_broad_ok);
+    const bool f32 = !g_opt.f64_broad || broad_reg_lds(m, S <= 8 ? 8 : (S <= 12 ? 12 : 16)) > 160 * 1024;   // the float64 form keeps its tables in LDS
     for (int64_t b0 = 0; b0 < B; b0 += tile) {
         const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
         const unsigned nblk = blocks_for(nb);
-        // worst case per sub-queue: every pair of every configuration of the blocks that map to it
         // a sub-queue takes one kind class of the blocks of one group (every 64th block): worst case all pairs of that class
         const unsigned long long cap_sub = sub_queue_cap(m, nblk);
         EdgeSrc es_tile = es;
-        if (es.map != nullptr) es_tile.map = es.map + b0;
+        if (es.map != nullptr) { es_tile.map = es.map + b0; es_tile.b0 = b0; }
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
         const double* qt = q ? q + b0 * m->n_q : nullptr;
         uint64_t* mb = mask_bits ? mask_bits + b0 / 64 : nullptr;
         uint8_t* my = mask_bytes ? mask_bytes + b0 : nullptr;
-        const int S = m->d.n_rshapes;
-        const bool use_reg = S <= 16 && (!getenv("NBK_NO_REG_BROAD") || !m->lds_broad_ok);
-        const bool f32 = !getenv("NBK_F64_BROAD") || broad_reg_lds(m, S <= 8 ? 8 : (S <= 12 ? 12 : 16)) > 160 * 1024;   // the float64 form keeps its tables in LDS
         float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
         const size_t qrows_f = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
         const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16;
         unsigned long long* count_next = nullptr;
         if (use_reg && f32) {
-            if (internal && mm->ws_ready && mm->ws_thr == threshold) {
+            if (internal && iw->ready && iw->thr == threshold) {
                 // tables are in place and the previous call's narrowphase cleared this call's counter set: no launch
-                count = count_set0 + (size_t)(mm->ws_epoch & 1u) * NSUB * CNT_STRIDE;
-                count_next = count_set0 + (size_t)((mm->ws_epoch + 1u) & 1u) * NSUB * CNT_STRIDE;
+                count = count_set0 + (size_t)(iw->epoch & 1u) * NSUB * CNT_STRIDE;
+                count_next = count_set0 + (size_t)((iw->epoch + 1u) & 1u) * NSUB * CNT_STRIDE;
             } else {
                 count = count_set0;
                 hipLaunchKernelGGL(k_prepare_f32, dim3(1), dim3(NSUB), 0, st, m->d, threshold, count_set0, internal ? 2 : 1, ftab);   // clears the counters too
-                if (internal) { mm->ws_ready = true; mm->ws_thr = threshold; mm->ws_epoch = 0; count_next = count_set0 + (size_t)NSUB * CNT_STRIDE; }
+                if (internal) { iw->ready = true; iw->thr = threshold; iw->epoch = 0; count_next = count_set0 + (size_t)NSUB * CNT_STRIDE; }
             }
-            if (internal) mm->ws_epoch += 1u;
+            if (internal) iw->epoch += 1u;
         } else {
             count = count_set0;
-            if (internal) mm->ws_ready = false;
+            if (internal) iw->ready = false;
             hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count);
         }
         if (use_reg && f32 && S <= 8)
@@ -3355,15 +3420,6 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const doub
         // workgroups per sub-queue: one 64-item chunk each at a few survivors per configuration; more chunks are strided over
         unsigned parts = 4u * nblk / NSUB;
         parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
-        // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
-        // distance predicate only, else the build with both
-        if (getenv("NBK_SORT_ITEMS")) hipLaunchKernelGGL(k_sort_items, dim3(NSUB), dim3(256), 0, st, m->d, atoi(getenv("NBK_SORT_ITEMS")), items, count, cap_sub);
-        bool any_zero = false, any_nonzero = false, any_negative = false;
-        for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
-            const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
-            if (tc == 0.0) any_zero = true; else any_nonzero = true;
-            if (!(tc > 0.0)) any_negative = true;          // (a NaN threshold counts as not positive)
-        }
         if (!any_nonzero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero && !any_negative)
@@ -3377,6 +3433,13 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const doub
     return NBK_OK;
 }
 
+static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+                                 uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw = nullptr) {
+    const int32_t rc = launch_two_kernel_impl(m, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, iw);
+    if (rc != NBK_OK && iw != nullptr) iw->ready = false;      // whatever state the queues are in: start over
+    return rc;
+}
+
 static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
     const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
     return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * (int64_t)sub_queue_cap(m, (unsigned long long)nblk);
@@ -3384,14 +3447,17 @@ static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
 
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
     if (m == nullptr || B < 0) return NBK_ERR_INVALID;
-    if ((B < two_kernel_min_b() && m->parked_ok) || m->n_pairs == 0 || B == 0) return 0;
+    if ((B < g_opt.two_kernel_min_b && m->parked_ok) || m->n_pairs == 0 || B == 0) return 0;
     // NSUB sub-queues, each sized for the blocks that map to it (rounded up)
     return two_kernel_workspace_bytes(m, B);
 }
 
+static const EdgeSrc NO_EDGES = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+
 int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                               uint8_t* mask_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && q == nullptr) || (mask_bits == nullptr && mask_bytes == nullptr)) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (B == 0) return NBK_OK;
     hipStream_t st = (hipStream_t)stream;
     const int64_t need = nbk_validity_workspace_bytes(m, B);
@@ -3402,8 +3468,7 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
         NBK_HIP(hipGetLastError());
         return NBK_OK;
     }
-    return launch_two_kernel(m, EdgeSrc{nullptr, nullptr, nullptr, nullptr}, q, B, threshold, mask_bits, mask_bytes, workspace, st,
-                             workspace == m->ws);      // the descriptor's own workspace: nbk_validity_batch holds its mutex
+    return launch_two_kernel(m, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, workspace, st);
 }
 
 int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
@@ -3411,25 +3476,35 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
     if (m == nullptr) return NBK_ERR_INVALID;
     const int64_t need = nbk_validity_workspace_bytes(m, B);
     if (need <= 0) return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, nullptr, 0, stream);
-    nbk_model* mm = const_cast<nbk_model*>(m);
-    std::lock_guard<std::mutex> lock(mm->mu);          // one internal workspace: calls on one model serialise here
-    { const int32_t e_ = internal_ws_enter(mm, (hipStream_t)stream); if (e_ != NBK_OK) return e_; }
-    if (mm->ws_bytes < (size_t)need) {
-        if (mm->ws) { NBK_HIP(hipStreamSynchronize((hipStream_t)stream)); NBK_HIP(hipDeviceSynchronize()); (void)hipFree(mm->ws); mm->ws = nullptr; mm->ws_bytes = 0; }
-        mm->ws_ready = false;
-        hipError_t e = hipMalloc(&mm->ws, (size_t)need);
-        if (e != hipSuccess) { hip_fail(e, "hipMalloc(workspace)"); return NBK_ERR_ALLOC; }
-        mm->ws_bytes = (size_t)need;
+    if (B < 0 || q == nullptr || (mask_bits == nullptr && mask_bytes == nullptr)) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
+    hipStream_t st = (hipStream_t)stream;
+    StreamWs* w = stream_ws(const_cast<nbk_model*>(m), st);
+    if (w == nullptr) { snprintf(g_err, sizeof(g_err), "more than 64 streams use this descriptor's internal workspaces: pass your own (nbk_validity_batch_ws)"); return NBK_ERR_ALLOC; }
+    std::lock_guard<std::mutex> lock(w->mu);
+    const bool capturing = stream_capturing(st);
+    if (w->ws_bytes < (size_t)need) {
+        if (capturing) {
+            snprintf(g_err, sizeof(g_err), "graph capture: this stream's internal workspace is not allocated yet -- run the call once "
+                     "outside the capture, or pass a workspace (nbk_validity_batch_ws)");
+            return NBK_ERR_UNSUPPORTED;
+        }
+        w->ready = false;
+        const int32_t rc = grow_scratch(st, w->ws, w->ws_bytes, (size_t)need, "hipMalloc(workspace)");
+        if (rc != NBK_OK) return rc;
     }
-    return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, mm->ws, (int64_t)mm->ws_bytes, stream);
+    // a captured call must be self-contained (it is replayed out of order with the host-side state): prepare + clear inside
+    // the graph, and the next direct call starts from scratch as well
+    if (capturing) w->ready = false;
+    return launch_two_kernel(m, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w);
 }
 
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || min_dist == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0) return NBK_OK;
-    static const bool brute = getenv("NBK_CLOSEST_BRUTE") != nullptr;
-    if (brute)
+    if (g_opt.closest_brute)
         hipLaunchKernelGGL(k_distances<0>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, min_dist,
                            argmin, (double*)nullptr);
     else
@@ -3442,6 +3517,7 @@ int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double
 
 int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     if (witness != nullptr)
@@ -3457,6 +3533,7 @@ int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B,
 int32_t nbk_proximity_jacobian_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, double* jrows,
                                      void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr || witness == nullptr || jrows == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     const size_t lds = collide_lds(m) + sizeof(double) * WAVE * 6 * (size_t)m->n_joints;
@@ -3467,79 +3544,184 @@ int32_t nbk_proximity_jacobian_batch(const nbk_model* m, const double* q, int64_
     return NBK_OK;
 }
 
-// edges below this count run one wave per edge (k_edges); measured slower than the flat batch even for a single edge
-// (0.42 ms vs 0.20 ms for a 300-sample edge), so the default sends everything through the batch path
-static inline int64_t edge_batch_min_e() { const char* e = getenv("NBK_EDGE_BATCH_MIN_E"); return e ? atoll(e) : 1; }
+// ---- batched DiscreteConnector: fully asynchronous -----------------------------------------------------------------------------
+// The sample count of an edge batch is only known on the device (the lengths come from device arrays), so nothing here waits
+// for it: the stream's edge scratch has a CAPACITY in samples, every launch covers the capacity and blocks beyond the true
+// count exit at once (EdgeSrc::total).  Capacity = E x (ceil(max_distance / resolution) + 2) samples at least -- exact for
+// steer, and for connect whenever the caller's edges respect the connector's max_distance (planners do) -- and at least 1.25 x
+// the count the previous call reported through pinned memory (`stats`, read here without waiting).  Edges that do not fit
+// anyway are marked and walked by one wave each (k_edges_overflow): always correct, only slower.
+static inline unsigned long long edge_capacity(int64_t E, double resolution, double max_distance) {
+    double per = ceil(max_distance / resolution) + 2.0;
+    if (!(per < 4096.0)) per = 4096.0;                    // an unbounded max_distance: start from 4096 samples per edge
+    double c = (double)E * per;
+    if (c < 4096.0) c = 4096.0;
+    if (c > 4.0e9) c = 4.0e9;
+    return ((unsigned long long)c + 63ull) & ~63ull;
+}
 
 int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const double* goals, const double* dist, int64_t E,
                                 double resolution, double max_distance, int32_t mode, double threshold, uint8_t* valid,
                                 double* end, int32_t* n_samples, void* stream) {
     if (m == nullptr || E < 0 || (E > 0 && (starts == nullptr || goals == nullptr || valid == nullptr))) return NBK_ERR_INVALID;
     if (!(resolution > 0.0) || !(max_distance > 0.0) || (mode != NBK_CONNECT && mode != NBK_STEER)) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (E == 0) return NBK_OK;
     if (E > 0x7fffffffLL) return NBK_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if ((E < edge_batch_min_e() && m->parked_ok) || m->n_pairs == 0) {
-        // a handful of edges: one wave per edge, early exit, one launch
+    if ((E < g_opt.edge_batch_min_e && m->parked_ok) || m->n_pairs == 0) {
+        // one wave per edge, early exit, one launch
         hipLaunchKernelGGL(k_edges, dim3((unsigned)E), dim3(WAVE), collide_lds(m), st, m->d, starts, goals, dist, E,
-                           resolution, max_distance, mode, threshold, valid, end, n_samples);
+                           resolution, max_distance, mode, threshold, valid, end, n_samples, (const uint8_t*)nullptr, (unsigned long long*)nullptr);
         NBK_HIP(hipGetLastError());
         return NBK_OK;
     }
-    // many edges: flat batch of all samples (this path synchronises once to learn the sample count and keeps
-    // its scratch in the descriptor: calls on one descriptor serialise)
-    nbk_model* mm = const_cast<nbk_model*>(m);
-    std::lock_guard<std::mutex> lock(mm->mu);
-    auto grow = [&](void*& buf, size_t& have, size_t need) -> int32_t {
-        if (have >= need) return NBK_OK;
-        if (buf) { NBK_HIP(hipDeviceSynchronize()); (void)hipFree(buf); buf = nullptr; have = 0; }
-        hipError_t e = hipMalloc(&buf, need);
-        if (e != hipSuccess) { hip_fail(e, "hipMalloc(edge scratch)"); return NBK_ERR_ALLOC; }
-        have = need;
-        return NBK_OK;
-    };
-    const size_t head = ((size_t)E * 3 * 8 + (size_t)(E + 1) * 8 * 2 + 4095) & ~size_t(4095);   // plan | cnt | offs
-    int32_t rc = grow(mm->ews, mm->ews_bytes, head);
-    if (rc != NBK_OK) return rc;
-    double* plan = static_cast<double*>(mm->ews);
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(plan + 3 * E);
-    unsigned long long* offs = cnt + (E + 1);
-    hipLaunchKernelGGL(k_edge_plan, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, m->n_q, starts, goals, dist, E, resolution,
-                       max_distance, mode, plan, cnt, end, n_samples);
-    NBK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, E, offs);
-    NBK_HIP(hipGetLastError());
-    unsigned long long total = 0;
-    NBK_HIP(hipMemcpyAsync(&total, offs + E, 8, hipMemcpyDeviceToHost, st));
-    NBK_HIP(hipStreamSynchronize(st));
-    if (total == 0) { NBK_HIP(hipMemsetAsync(valid, 0, (size_t)E, st)); return NBK_OK; }
-    const size_t map_bytes = ((size_t)total * 8 + 4095) & ~size_t(4095);
-    const size_t words_bytes = (((size_t)total + 63) / 64 * 8 + 4095) & ~size_t(4095);
-    // the header must survive a reallocation: grow first, then recompute it if the buffer moved
-    if (mm->ews_bytes < head + map_bytes + words_bytes) {
-        rc = grow(mm->ews, mm->ews_bytes, head + map_bytes + words_bytes);
-        if (rc != NBK_OK) return rc;
-        plan = static_cast<double*>(mm->ews);
-        cnt = reinterpret_cast<unsigned long long*>(plan + 3 * E);
-        offs = cnt + (E + 1);
+    StreamWs* w = stream_ws(const_cast<nbk_model*>(m), st);
+    if (w == nullptr) { snprintf(g_err, sizeof(g_err), "more than 64 streams use this descriptor's internal workspaces"); return NBK_ERR_ALLOC; }
+    std::lock_guard<std::mutex> lock(w->mu);
+    const bool capturing = stream_capturing(st);
+    // capacity: the static bound, and what earlier calls on this stream turned out to need (pinned memory, not waited for)
+    unsigned long long cap = edge_capacity(E, resolution, max_distance);
+    if (w->stats != nullptr && __atomic_load_n(&w->stats[1], __ATOMIC_RELAXED) != 0ull) {
+        // the last finished call had edges that did not fit: leave headroom over what it needed
+        const unsigned long long seen = __atomic_load_n(&w->stats[0], __ATOMIC_RELAXED);
+        const unsigned long long want = seen + seen / 4;
+        if (want > cap && want < 4000000000ull) cap = (want + 63ull) & ~63ull;
+    }
+    if (!m->parked_ok) {
+        // robots whose primitives do not fit the one-wave-per-edge kernel cannot serve overflowing edges: such descriptors
+        // keep a synchronous sizing step (one read-back) and cannot be captured
+        if (capturing) { snprintf(g_err, sizeof(g_err), "graph capture of edge batches needs a robot that fits the LDS-parked layout"); return NBK_ERR_UNSUPPORTED; }
+    }
+    double* plan = nullptr;
+    unsigned long long *cnt = nullptr, *offs = nullptr, *map = nullptr;
+    uint8_t* ovf = nullptr;
+    uint64_t* words = nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const bool fits = w->ecap_edges >= E && w->ecap_samples >= cap && w->stats != nullptr &&
+                          w->ws_bytes >= (size_t)two_kernel_workspace_bytes(m, (int64_t)w->ecap_samples);
+        if (!fits) {
+            if (capturing) {
+                snprintf(g_err, sizeof(g_err), "graph capture: this stream's edge scratch is not allocated for %lld edges yet -- run the "
+                         "call once outside the capture", (long long)E);
+                return NBK_ERR_UNSUPPORTED;
+            }
+            if (w->stats == nullptr) {
+                NBK_HIP(hipHostMalloc((void**)&w->stats, 4 * sizeof(unsigned long long), hipHostMallocMapped));
+                memset(w->stats, 0, 4 * sizeof(unsigned long long));
+                NBK_HIP(hipHostGetDevicePointer((void**)&w->stats_dev, w->stats, 0));
+            }
+            const long long ne = w->ecap_edges > E ? w->ecap_edges : E;
+            const unsigned long long nc = w->ecap_samples > cap ? w->ecap_samples : cap;
+            const size_t head_n = ((size_t)ne * 3 * 8 + (size_t)(ne + 1) * 8 * 2 + (size_t)ne + 4095) & ~size_t(4095);   // plan | cnt | offs | overflow flags
+            const size_t map_n = ((size_t)nc * 8 + 4095) & ~size_t(4095);
+            const size_t words_n = (((size_t)nc + 63) / 64 * 8 + 4095) & ~size_t(4095);
+            int32_t rc = grow_scratch(st, w->ews, w->ews_bytes, head_n + map_n + words_n, "hipMalloc(edge scratch)");
+            if (rc != NBK_OK) return rc;
+            w->ecap_edges = ne; w->ecap_samples = nc;
+            const size_t need = (size_t)two_kernel_workspace_bytes(m, (int64_t)nc);
+            if (w->ws_bytes < need) {
+                w->ready = false;
+                rc = grow_scratch(st, w->ws, w->ws_bytes, need, "hipMalloc(workspace)");
+                if (rc != NBK_OK) return rc;
+            }
+        }
+        cap = w->ecap_samples;                                 // use all of what is there
+        const size_t head_c = ((size_t)w->ecap_edges * 3 * 8 + (size_t)(w->ecap_edges + 1) * 8 * 2 + (size_t)w->ecap_edges + 4095) & ~size_t(4095);
+        const size_t map_c = ((size_t)cap * 8 + 4095) & ~size_t(4095);
+        plan = static_cast<double*>(w->ews);
+        cnt = reinterpret_cast<unsigned long long*>(plan + 3 * w->ecap_edges);
+        offs = cnt + (w->ecap_edges + 1);
+        ovf = reinterpret_cast<uint8_t*>(offs + (w->ecap_edges + 1));
+        map = reinterpret_cast<unsigned long long*>(static_cast<char*>(w->ews) + head_c);
+        words = reinterpret_cast<uint64_t*>(static_cast<char*>(w->ews) + head_c + map_c);
         hipLaunchKernelGGL(k_edge_plan, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, m->n_q, starts, goals, dist, E, resolution,
                            max_distance, mode, plan, cnt, end, n_samples);
+        NBK_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, cnt, E, offs);
         NBK_HIP(hipGetLastError());
+        if (m->parked_ok) break;
+        // (see above) no overflow kernel for this robot: size exactly, with one read-back
+        unsigned long long total = 0;
+        NBK_HIP(hipMemcpyAsync(&total, offs + E, 8, hipMemcpyDeviceToHost, st));
+        NBK_HIP(hipStreamSynchronize(st));
+        if (total <= cap) break;
+        if (attempt == 1 || total >= 4000000000ull) { snprintf(g_err, sizeof(g_err), "edge batch of %llu samples is too large", total); return NBK_ERR_UNSUPPORTED; }
+        cap = (total + 63ull) & ~63ull;
     }
-    unsigned long long* map = reinterpret_cast<unsigned long long*>(static_cast<char*>(mm->ews) + head);
-    uint64_t* words = reinterpret_cast<uint64_t*>(static_cast<char*>(mm->ews) + head + map_bytes);
-    { const int32_t e_ = internal_ws_enter(mm, st); if (e_ != NBK_OK) return e_; }
-    if (mm->ws_bytes < (size_t)two_kernel_workspace_bytes(m, (int64_t)total)) mm->ws_ready = false;     // about to be reallocated
-    rc = grow(mm->ws, mm->ws_bytes, (size_t)two_kernel_workspace_bytes(m, (int64_t)total));
-    if (rc != NBK_OK) return rc;
-    hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, map);
+    hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, map, cap, ovf);
     NBK_HIP(hipGetLastError());
-    EdgeSrc es{starts, goals, plan, map};
-    rc = launch_two_kernel(m, es, nullptr, (int64_t)total, threshold, words, nullptr, mm->ws, st, true);
+    EdgeSrc es{starts, goals, plan, map, offs + E, 0};
+    if (capturing) w->ready = false;
+    const int32_t rc = launch_two_kernel(m, es, nullptr, (int64_t)cap, threshold, words, nullptr, w->ws, st, capturing ? nullptr : w);
     if (rc != NBK_OK) return rc;
-    hipLaunchKernelGGL(k_edge_reduce, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, words, valid);
+    hipLaunchKernelGGL(k_edge_reduce, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, words, ovf, valid, w->stats_dev);
     NBK_HIP(hipGetLastError());
+    if (m->parked_ok) {
+        hipLaunchKernelGGL(k_edges, dim3((unsigned)E), dim3(WAVE), collide_lds(m), st, m->d, starts, goals, dist, E,
+                           resolution, max_distance, mode, threshold, valid, (double*)nullptr, (int32_t*)nullptr, (const uint8_t*)ovf, w->stats_dev);
+        NBK_HIP(hipGetLastError());
+    }
+    return NBK_OK;
+}
+
+// ---- scalar calls from host memory (Arm.in_collision(q), DiscreteConnector.connect(a, b) on one configuration / one edge) ----
+// The reference's planners call these once per sample / per edge (numbotics/planning/sampling_based/prm.py:40,
+// connectors.py:57-100), so what counts is latency: inputs and results travel through pinned host memory that the kernels
+// read and write directly (no staging copies), on a private stream with its own scratch set; one wait at the end.
+static int32_t scalar_setup(nbk_model* mm) {
+    if (mm->scalar_q != nullptr) return NBK_OK;
+    const size_t nd = 4 * (size_t)mm->n_q + 8;
+    NBK_HIP(hipHostMalloc((void**)&mm->scalar_q, nd * sizeof(double), hipHostMallocMapped));
+    NBK_HIP(hipHostMalloc((void**)&mm->scalar_out, 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    NBK_HIP(hipStreamCreateWithFlags(&mm->scalar_stream, hipStreamNonBlocking));
+    return NBK_OK;
+}
+
+int32_t nbk_validity_scalar_host(const nbk_model* m, const double* q, double threshold, int32_t* in_collision) {
+    if (m == nullptr || q == nullptr || in_collision == nullptr) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
+    nbk_model* mm = const_cast<nbk_model*>(m);
+    std::lock_guard<std::mutex> lock(mm->scalar_mu);
+    { const int32_t rc = scalar_setup(mm); if (rc != NBK_OK) return rc; }
+    memcpy(mm->scalar_q, q, sizeof(double) * (size_t)m->n_q);
+    double* dq = nullptr;
+    uint64_t* dout = nullptr;
+    NBK_HIP(hipHostGetDevicePointer((void**)&dq, mm->scalar_q, 0));
+    NBK_HIP(hipHostGetDevicePointer((void**)&dout, mm->scalar_out, 0));
+    mm->scalar_out[0] = 0ull;
+    const int32_t rc = nbk_validity_batch(m, dq, 1, threshold, dout, nullptr, mm->scalar_stream);
+    if (rc != NBK_OK) return rc;
+    NBK_HIP(hipStreamSynchronize(mm->scalar_stream));
+    *in_collision = (int32_t)(mm->scalar_out[0] & 1ull);
+    return NBK_OK;
+}
+
+int32_t nbk_edge_validity_scalar_host(const nbk_model* m, const double* start, const double* goal, double dist, double resolution,
+                                      double max_distance, int32_t mode, double threshold, int32_t* valid, double* end,
+                                      int32_t* n_samples) {
+    if (m == nullptr || start == nullptr || goal == nullptr || valid == nullptr) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
+    nbk_model* mm = const_cast<nbk_model*>(m);
+    std::lock_guard<std::mutex> lock(mm->scalar_mu);
+    { const int32_t rc = scalar_setup(mm); if (rc != NBK_OK) return rc; }
+    const size_t nq = (size_t)m->n_q;
+    double* h = mm->scalar_q;                           // start | goal | end | dist
+    memcpy(h, start, sizeof(double) * nq);
+    memcpy(h + nq, goal, sizeof(double) * nq);
+    h[3 * nq] = dist;
+    double* d = nullptr;
+    unsigned long long* dout = nullptr;
+    NBK_HIP(hipHostGetDevicePointer((void**)&d, mm->scalar_q, 0));
+    NBK_HIP(hipHostGetDevicePointer((void**)&dout, mm->scalar_out, 0));
+    const bool has_dist = dist >= 0.0 || dist != dist;      // a negative value = "Euclidean norm" (a NaN length is a given length)
+    const int32_t rc = nbk_edge_validity_batch(m, d, d + nq, has_dist ? d + 3 * nq : nullptr, 1, resolution, max_distance, mode, threshold,
+                                               reinterpret_cast<uint8_t*>(dout), d + 2 * nq, reinterpret_cast<int32_t*>(dout + 1), mm->scalar_stream);
+    if (rc != NBK_OK) return rc;
+    NBK_HIP(hipStreamSynchronize(mm->scalar_stream));
+    *valid = (int32_t)(reinterpret_cast<const uint8_t*>(mm->scalar_out)[0]);
+    if (end != nullptr) memcpy(end, h + 2 * nq, sizeof(double) * nq);
+    if (n_samples != nullptr) *n_samples = reinterpret_cast<const int32_t*>(mm->scalar_out + 1)[0];
     return NBK_OK;
 }
 
@@ -3556,6 +3738,7 @@ int32_t nbk_selftest_math(const double* a, const double* b, int64_t n, double* s
 int32_t nbk_fk_batch_host(const nbk_model* m, const double* q, int64_t B, const int32_t* path, int32_t path_len,
                           const double* local, double* T_out) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || T_out == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (B == 0) return NBK_OK;
     double *dq = nullptr, *dT = nullptr;
     NBK_HIP(hipMalloc((void**)&dq, sizeof(double) * B * m->n_q));
@@ -3572,6 +3755,7 @@ int32_t nbk_fk_batch_host(const nbk_model* m, const double* q, int64_t B, const 
 
 int32_t nbk_validity_batch_host(const nbk_model* m, const double* q, int64_t B, double threshold, uint8_t* mask_bytes) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || mask_bytes == nullptr))) return NBK_ERR_INVALID;
+    NBK_DEVICE(m);
     if (B == 0) return NBK_OK;
     double* dq = nullptr;
     uint8_t* dm = nullptr;

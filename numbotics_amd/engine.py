@@ -229,6 +229,31 @@ class DeviceModel:
                                                        self._stream()), "nbk_validity_batch_ws")
         return qs.out(words) if packed else qs.out(mask.bool())
 
+    def validity_scalar(self, q, threshold=0.0) -> bool:
+        """One configuration from host memory (the reference's scalar ``in_collision(q)``): pinned, device-mapped staging
+        inside the library, one wait -- no torch tensors on the way."""
+        a = np.ascontiguousarray(q, dtype=np.float64).reshape(-1)
+        if a.size != self.n_q:
+            raise ValueError(f"expected {self.n_q} values, got {a.size}")
+        out = C.c_int32(0)
+        _lib.check(self._lib.nbk_validity_scalar_host(self._h, a.ctypes.data, float(threshold), C.byref(out)),
+                   "nbk_validity_scalar_host")
+        return bool(out.value)
+
+    def edge_validity_scalar(self, start, goal, resolution, max_distance, mode="connect", threshold=0.0, dist=None):
+        """One edge from host memory -> (valid, end state (n_q,), samples)."""
+        s = np.ascontiguousarray(start, dtype=np.float64).reshape(-1)
+        g = np.ascontiguousarray(goal, dtype=np.float64).reshape(-1)
+        if s.size != self.n_q or g.size != self.n_q:
+            raise ValueError(f"expected {self.n_q} values per end point")
+        end = np.empty((self.n_q,), dtype=np.float64)
+        ok, ns = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._lib.nbk_edge_validity_scalar_host(
+            self._h, s.ctypes.data, g.ctypes.data, -1.0 if dist is None else float(dist), float(resolution), float(max_distance),
+            0 if mode == "connect" else 1, float(threshold), C.byref(ok), end.ctypes.data, C.byref(ns)),
+            "nbk_edge_validity_scalar_host")
+        return bool(ok.value), end, int(ns.value)
+
     def closest(self, q):
         torch = _require_gpu()
         qs = _Staged(q, self.n_q)

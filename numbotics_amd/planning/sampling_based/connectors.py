@@ -79,8 +79,8 @@ class DiscreteConnector(Connector):
         if distance <= np.finfo(np.float32).eps:
             return None
         if self._device_edge():
-            ok, _, _ = self._batch(start[None], goal[None], "connect", np.array([distance], dtype=np.float64))
-            return np.copy(goal) if bool(ok[0]) else None
+            ok, _, _ = self._scalar(start, goal, "connect", distance)
+            return np.copy(goal) if ok else None
         if self._walk(start, goal, distance, 1.0) is None:
             return None
         return np.copy(goal)
@@ -90,8 +90,8 @@ class DiscreteConnector(Connector):
         if distance <= np.finfo(np.float32).eps:
             return None
         if self._device_edge():
-            ok, end, _ = self._batch(start[None], goal[None], "steer", np.array([distance], dtype=np.float64))
-            return np.copy(end[0]) if bool(ok[0]) else None
+            ok, end, _ = self._scalar(start, goal, "steer", distance)
+            return end if ok else None
         T_f = 1.0 if distance <= self._params.max_distance else self._params.max_distance / distance
         trajectory = self._walk(start, goal, distance, T_f)
         if trajectory is None:
@@ -103,6 +103,16 @@ class DiscreteConnector(Connector):
         if p.validity_checker is not None:
             return p.validity_checker(state)
         return not p.arm.in_collision(state, p.collision_threshold)
+
+    def _scalar(self, start, goal, mode, distance):
+        """One edge, every sample in one device call (host arrays through the library's pinned staging)."""
+        p = self._params
+        _, dev = p.arm._scene_device()
+        if isinstance(start, np.ndarray) and isinstance(goal, np.ndarray):
+            return dev.edge_validity_scalar(start, goal, p.resolution, p.max_distance, mode=mode,
+                                            threshold=p.collision_threshold, dist=float(distance))
+        ok, end, ns = self._batch(start[None], goal[None], mode, np.array([distance], dtype=np.float64))
+        return bool(ok[0]), np.copy(end[0]), int(ns[0])
 
     # ---- batched (additive) ------------------------------------------------------------------------------
     def _batch(self, starts, goals, mode, dist=None):

@@ -453,6 +453,8 @@ class Arm(Robot):
         if q.ndim == 1:
             if sm.n_pairs == 0:
                 raise ValueError("min() arg is an empty sequence")       # what upstream's closest_to raises
+            if isinstance(q, np.ndarray):
+                return dev.validity_scalar(q, threshold)                 # host fast path: pinned staging, one wait
             return bool(dev.validity(q.reshape(1, -1), threshold)[0])
         mask = dev.validity(q.reshape(-1, self.dof), threshold)
         return mask.reshape(tuple(q.shape[:-1]))

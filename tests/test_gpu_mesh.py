@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle.cpu_oracle import Oracle
 from numbotics_amd.scenes import build_scene, sample_q
+from numbotics_amd._lib import debug_option
 from test_gpu_parity import assert_bitwise, fused_path, torch_cuda      # noqa: F401  (fixture)
 
 
@@ -28,11 +29,8 @@ def test_mesh_validity_through_all_three_paths(fresh_world, scene, torch_cuda):
         assert np.array_equal(arm.in_collision(q, thr), ref), (scene, thr, "float32 broadphase + narrowphase")
         with fused_path():
             assert np.array_equal(arm.in_collision(q[:4096], thr), ref[:4096]), (scene, thr, "fused kernel")
-        os.environ["NBK_F64_BROAD"] = "1"
-        try:
+        with debug_option("f64_broad", 1):
             assert np.array_equal(arm.in_collision(q, thr), ref), (scene, thr, "float64 broadphase")
-        finally:
-            del os.environ["NBK_F64_BROAD"]
     ref0 = orc.validity(q, 0.0, nthreads=8)
     assert 0.03 < ref0.mean() < 0.6
     need = dev.validity_workspace_bytes(20000)
@@ -131,11 +129,8 @@ def test_random_mechanisms_with_mesh_links_among_mesh_obstacles(fresh_world, see
         assert np.array_equal(arm.in_collision(q, thr), ref), f"two-kernel path, thr {thr}"
         with fused_path():
             assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), f"fused path, thr {thr}"
-        os.environ["NBK_NO_REG_BROAD"] = "1"
-        try:
+        with debug_option("no_reg_broad", 1):
             assert np.array_equal(arm.in_collision(q, thr), ref), f"LDS broadphase, thr {thr}"
-        finally:
-            del os.environ["NBK_NO_REG_BROAD"]
     d, w, rows = arm.proximity_jacobians(q[:600])
     dr, wr, rr = orc.proximity_jacobian(q[:600])
     assert_bitwise(d, dr, "fuzz distances")

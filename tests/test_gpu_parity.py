@@ -7,6 +7,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle.cpu_oracle import Oracle, sincos, sqrt_div
 from numbotics_amd.scenes import build_scene, sample_q
+from numbotics_amd._lib import debug_option
 
 
 @pytest.fixture(scope="module")
@@ -24,12 +25,12 @@ class fused_path:
     """Route small batches through the fused kernel k_validity (the default sends every size through broadphase + narrowphase)."""
 
     def __enter__(self):
-        import os
-        os.environ["NBK_TWO_KERNEL_MIN_B"] = "1000000000"
+        from numbotics_amd._lib import set_debug_option
+        set_debug_option("two_kernel_min_b", 10 ** 9)
 
     def __exit__(self, *exc):
-        import os
-        del os.environ["NBK_TWO_KERNEL_MIN_B"]
+        from numbotics_amd._lib import set_debug_option
+        set_debug_option("two_kernel_min_b", 1)
         return False
 
 
@@ -143,12 +144,9 @@ def test_fused_and_two_kernel_paths_agree(fresh_world, torch_cuda):
     for thr in (0.0, 0.01, -0.002):
         big = dev.validity(q, thr)                                        # broadphase + narrowphase
         small = np.concatenate([dev.validity(q[i:i + 4096], thr) for i in range(0, 40000, 4096)])
-        os.environ["NBK_TWO_KERNEL_MIN_B"] = "1000000"
-        try:
+        with debug_option("two_kernel_min_b", 1000000):
             assert dev.validity_workspace_bytes(4096) == 0
             fused = np.concatenate([dev.validity(q[i:i + 4096], thr) for i in range(0, 40000, 4096)])   # fused kernel
-        finally:
-            del os.environ["NBK_TWO_KERNEL_MIN_B"]
         assert np.array_equal(big, small) and np.array_equal(big, fused)
         assert np.array_equal(big, orc.validity(q, thr, nthreads=8))
     need = dev.validity_workspace_bytes(40000)
@@ -232,15 +230,12 @@ def test_one_wave_per_edge_kernel_still_agrees(fresh_world, torch_cuda):
     orc = Oracle(arm.scene_model())
     _, dev = arm._scene_device()
     q = sample_q(chain, 60, seed=44)
-    os.environ["NBK_EDGE_BATCH_MIN_E"] = "1000"
-    try:
+    with debug_option("edge_batch_min_e", 1000):
         for mode in ("connect", "steer"):
             ok, end, ns = dev.edge_validity(q[:30], q[30:], 0.02, 1.0, mode=mode)
             okr, endr, nsr = orc.edge_validity(q[:30], q[30:], 0.02, 1.0, mode=mode)
             assert np.array_equal(ok, okr) and np.array_equal(ns, nsr)
             assert_bitwise(end, endr, "k_edges end states")
-    finally:
-        del os.environ["NBK_EDGE_BATCH_MIN_E"]
 
 
 @pytest.mark.parametrize("mode", ["connect", "steer"])
@@ -359,11 +354,8 @@ def test_tree_robot_with_prismatic_joints(fresh_world, torch_cuda):
         assert np.array_equal(arm.in_collision(q, thr), ref)                        # register broadphase
         with fused_path():
             assert np.array_equal(np.concatenate([arm.in_collision(q[i:i + 4000], thr) for i in range(0, 12000, 4000)]), ref)  # fused
-        os.environ["NBK_NO_REG_BROAD"] = "1"
-        try:
+        with debug_option("no_reg_broad", 1):
             assert np.array_equal(arm.in_collision(q, thr), ref)                    # LDS broadphase
-        finally:
-            del os.environ["NBK_NO_REG_BROAD"]
     assert 0.02 < orc.validity(q).mean() < 0.98
     assert_bitwise(arm.pair_distances(q[:1000]), orc.pair_distances(q[:1000]), "tree distances")
     _, dev = arm._scene_device()
@@ -688,11 +680,8 @@ def test_random_mechanisms_and_scenes(fresh_world, seed, torch_cuda, tmp_path):
         assert np.array_equal(arm.in_collision(q, thr), ref), f"two-kernel path, thr {thr}"
         with fused_path():
             assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), f"fused path, thr {thr}"
-        os.environ["NBK_NO_REG_BROAD"] = "1"
-        try:
+        with debug_option("no_reg_broad", 1):
             assert np.array_equal(arm.in_collision(q, thr), ref), f"LDS broadphase, thr {thr}"
-        finally:
-            del os.environ["NBK_NO_REG_BROAD"]
     d, w, rows = arm.proximity_jacobians(q[:600])
     dr, wr, rr = orc.proximity_jacobian(q[:600])
     assert_bitwise(d, dr, "fuzz distances")
@@ -895,12 +884,9 @@ def test_non_finite_joint_values_count_as_colliding(fresh_world, torch_cuda):
     assert np.array_equal(arm.in_collision(q, 0.0), ref)                       # float32 broadphase
     with fused_path():
         assert np.array_equal(arm.in_collision(q[:3000], 0.0), ref[:3000])         # fused kernel
-    for flag in ("NBK_F64_BROAD", "NBK_NO_REG_BROAD"):                         # float64 register / LDS broadphase
-        os.environ[flag] = "1"
-        try:
+    for flag in ("f64_broad", "no_reg_broad"):                         # float64 register / LDS broadphase
+        with debug_option(flag, 1):
             assert np.array_equal(arm.in_collision(q, 0.0), ref), flag
-        finally:
-            del os.environ[flag]
     _, dev = arm._scene_device()
     s_, g_ = q[:200].copy(), q[200:400].copy()
     ok, end, ns = dev.edge_validity(s_, g_, 0.05, 1.5, mode="connect")
@@ -1147,3 +1133,151 @@ def test_ten_million_batch_is_tiled_correctly(fresh_world, torch_cuda):
     half = 5_000_000 - 5_000_000 % 64
     w2 = torch.cat([dev.validity(q[:half], 0.0, packed=True), dev.validity(q[half:], 0.0, packed=True)])
     assert torch.equal(w, w2)
+
+
+def test_two_streams_share_one_arm(fresh_world, torch_cuda):
+    """Every stream gets its own scratch set inside the descriptor: validity and edge batches issued from two torch
+    streams without any synchronisation in between produce the bits of the serial run (no shared plan / queue / mask scratch)."""
+    torch = torch_cuda
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    q = sample_q(chain, 120000, seed=71)
+    qa, qb = torch.from_numpy(q[:60000]).cuda(), torch.from_numpy(q[60000:]).cuda()
+    ea = (torch.from_numpy(q[:3000]).cuda(), torch.from_numpy(q[3000:6000]).cuda())
+    eb = (torch.from_numpy(q[6000:9000]).cuda(), torch.from_numpy(q[9000:12000]).cuda())
+    ref_a, ref_b = orc.validity(q[:60000], nthreads=8), orc.validity(q[60000:], nthreads=8)
+    ref_ea = orc.edge_validity(q[:3000], q[3000:6000], 0.03, 2.0, nthreads=8)[0]
+    ref_eb = orc.edge_validity(q[6000:9000], q[9000:12000], 0.03, 2.0, nthreads=8)[0]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(4):
+        with torch.cuda.stream(s1):
+            va = dev.validity(qa, 0.0)
+            oka = dev.edge_validity(ea[0], ea[1], 0.03, 2.0)[0]
+        with torch.cuda.stream(s2):
+            okb = dev.edge_validity(eb[0], eb[1], 0.03, 2.0)[0]
+            vb = dev.validity(qb, 0.0)
+        outs.append((va, oka, okb, vb))
+    torch.cuda.synchronize()
+    for va, oka, okb, vb in outs:
+        assert np.array_equal(va.cpu().numpy(), ref_a) and np.array_equal(vb.cpu().numpy(), ref_b)
+        assert np.array_equal(oka.cpu().numpy(), ref_ea) and np.array_equal(okb.cpu().numpy(), ref_eb)
+
+
+def test_internal_workspace_calls_are_capturable_once_allocated(fresh_world, torch_cuda):
+    """nbk_validity_batch and nbk_edge_validity_batch inside a hipGraph: refused (status, no allocation inside the capture)
+    before the stream's scratch exists; after one direct call they are self-contained graph nodes that replay bit-exactly on
+    new inputs, and direct calls afterwards still work."""
+    import ctypes as C
+    torch = torch_cuda
+    from numbotics_amd import _lib
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    lib = _lib.load()
+    B, E = 30000, 2000
+    q = torch.from_numpy(sample_q(chain, B, seed=5)).cuda()
+    s = torch.from_numpy(sample_q(chain, E, seed=6)).cuda()
+    g = torch.from_numpy(sample_q(chain, E, seed=7)).cuda()
+    words = torch.zeros(((B + 63) // 64,), dtype=torch.int64, device="cuda")
+    valid = torch.zeros((E,), dtype=torch.uint8, device="cuda")
+    end = torch.zeros((E, 7), dtype=torch.float64, device="cuda")
+    ns = torch.zeros((E,), dtype=torch.int32, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+
+    def calls(st):
+        r1 = lib.nbk_validity_batch(dev._h, q.data_ptr(), B, 0.0, words.data_ptr(), None, st)
+        r2 = lib.nbk_edge_validity_batch(dev._h, s.data_ptr(), g.data_ptr(), None, E, 0.02, 2.5, 1, 0.0, valid.data_ptr(),
+                                         end.data_ptr(), ns.data_ptr(), st)
+        return r1, r2
+    g0 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        sst = C.c_void_p(side.cuda_stream)
+        # 1. capture on a stream that has no scratch yet: refused with a status code, nothing allocated, capture stays valid
+        g0.capture_begin()
+        assert calls(sst) == (-4, -4)
+        g0.capture_end()
+        # 2. one direct call allocates this stream's scratch
+        assert calls(sst) == (0, 0)
+        side.synchronize()
+        ref_words, ref_valid = words.clone(), valid.clone()
+        assert np.array_equal(ref_valid.cpu().numpy().astype(bool), orc.edge_validity(s.cpu().numpy(), g.cpu().numpy(), 0.02, 2.5, mode="steer", nthreads=8)[0])
+        # 3. capture for real
+        g1 = torch.cuda.CUDAGraph()
+        g1.capture_begin()
+        assert calls(sst) == (0, 0)
+        g1.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    words.zero_(); valid.zero_()
+    g1.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(words, ref_words) and torch.equal(valid, ref_valid)
+    # new inputs, same graph -- twice, so that a replay also follows a replay
+    for seed in (15, 25):
+        q.copy_(torch.from_numpy(sample_q(chain, B, seed=seed)).cuda())
+        s.copy_(torch.from_numpy(sample_q(chain, E, seed=seed + 1)).cuda())
+        g.copy_(torch.from_numpy(sample_q(chain, E, seed=seed + 2)).cuda())
+        g1.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(words.cpu().numpy(), dev.validity(q, 0.0, packed=True).cpu().numpy())
+        okr, endr, nsr = orc.edge_validity(s.cpu().numpy(), g.cpu().numpy(), 0.02, 2.5, mode="steer", nthreads=8)
+        assert np.array_equal(valid.cpu().numpy().astype(bool), okr) and np.array_equal(ns.cpu().numpy(), nsr)
+        assert_bitwise(end.cpu().numpy(), endr, "captured steer end states")
+    # direct calls on the capture stream still work after the capture (its cached state was dropped)
+    with torch.cuda.stream(side):
+        assert calls(C.c_void_p(side.cuda_stream)) == (0, 0)
+    side.synchronize()
+    assert np.array_equal(words.cpu().numpy(), dev.validity(q, 0.0, packed=True).cpu().numpy())
+
+
+def test_edge_batches_beyond_the_scratch_capacity(fresh_world, torch_cuda):
+    """connect() edges far longer than max_distance: the flat batch's capacity (E x (max_distance / resolution + 2) samples)
+    overflows, the edges that do not fit are walked one wave each -- same bits; the device reports the true count through
+    pinned memory and the next call sizes its scratch from it."""
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    rng = np.random.default_rng(3)
+    base = sample_q(chain, 1, seed=9)[0] * 0.2
+    s_ = base + rng.uniform(-0.3, 0.3, (400, 7))
+    g_ = s_ + rng.uniform(-1.0, 1.0, (400, 7)) * rng.uniform(0.1, 3.0, (400, 1))         # lengths up to ~5 rad
+    okr, endr, nsr = orc.edge_validity(s_, g_, 0.01, 0.25, mode="connect", nthreads=8)
+    assert nsr.sum() > 3 * 400 * 27 and 0 < okr.sum() < 400                      # well beyond E * (0.25 / 0.01 + 2) samples
+    for rep in range(3):                                                          # first call overflows, later ones have grown
+        ok, end, ns = dev.edge_validity(s_, g_, 0.01, 0.25, mode="connect")
+        assert np.array_equal(ok, okr) and np.array_equal(ns, nsr), rep
+        assert_bitwise(end, endr, "overflow edge ends")
+    ok, end, ns = dev.edge_validity(s_, g_, 0.01, 0.25, mode="steer")
+    okr, endr, nsr = orc.edge_validity(s_, g_, 0.01, 0.25, mode="steer", nthreads=8)
+    assert np.array_equal(ok, okr) and np.array_equal(ns, nsr) and nsr.max() <= 27
+    assert_bitwise(end, endr, "steer ends")
+
+
+def test_scalar_host_paths(fresh_world, torch_cuda):
+    """Arm.in_collision(q) / DiscreteConnector.connect / steer on single host arrays run through the library's pinned
+    staging (nbk_validity_scalar_host / nbk_edge_validity_scalar_host): same answers as the oracle and as the batch path."""
+    from numbotics_amd.planning.sampling_based import ConnectorParams, DiscreteConnector
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    q = sample_q(chain, 300, seed=77)
+    ref = orc.validity(q)
+    got = np.array([arm.in_collision(q[i]) for i in range(300)])
+    assert np.array_equal(got, ref) and 0 < ref.sum() < 300
+    assert np.array_equal(np.array([arm.in_collision(q[i], 0.05) for i in range(100)]), orc.validity(q[:100], 0.05))
+    assert arm.in_collision(np.full(7, np.nan)) is True
+    conn = DiscreteConnector(ConnectorParams(resolution=0.02, max_distance=1.0, arm=arm))
+    okr, endr, nsr = orc.edge_validity(q[:100], q[100:200], 0.02, 1.0, mode="connect")
+    oks, ends, _ = orc.edge_validity(q[:100], q[100:200], 0.02, 1.0, mode="steer")
+    for i in range(100):
+        c = conn.connect(q[i], q[100 + i])
+        assert (c is not None) == bool(okr[i]) and (c is None or np.array_equal(c, q[100 + i]))
+        st = conn.steer(q[i], q[100 + i])
+        assert (st is not None) == bool(oks[i]) and (st is None or np.array_equal(st, ends[i]))
+    assert conn.connect(q[0], q[0]) is None                                   # d <= float32 eps
+    _, dev = arm._scene_device()
+    ok, end, ns = dev.edge_validity_scalar(q[3], q[150], 0.02, 1.0, mode="steer")
+    o1, e1, n1 = orc.edge_validity(q[3:4], q[150:151], 0.02, 1.0, mode="steer")
+    assert (ok, ns) == (bool(o1[0]), int(n1[0])) and np.array_equal(end, e1[0])
