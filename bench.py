@@ -3,17 +3,24 @@
 
 Workload (BASELINE.json configs[1]): Kinova-like 7-DoF arm, Arm.in_collision over a 1e6-q batch per GPU,
 self pairs (default rule minus the removals of _test_rrt.py:38-61) + one Cube(half_extent=0.4) at
-[1.0, 0.0, 0.2], threshold 0.  One "step" = one pass of the hot path over the batch: the validity kernel
-writing the packed bit mask, and for N > 1 the RCCL all-gather of every rank's mask words.
+[1.0, 0.0, 0.2], threshold 0.  One "step" = one pass of the hot path over one batch: the validity kernels
+writing the packed bit mask, and for N > 1 the RCCL all-gather of every rank's mask words.  The timed loop rotates
+over 5 distinct q batches (5 x 56 MB = 280 MB > the 256 MiB Infinity Cache), so no step finds its input in cache.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B | --global-batch G]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line.  `roofline` prices the validity kernel against HBM as the contract asks
-(algorithmic bytes = 56 B of q + 1 bit of mask per configuration); the kernel is VALU-bound by
-construction, so the float64 VALU fraction is reported next to it, and the HBM-bound
-pose-writing FK kernel gets its own roofline object.  `cpu_baseline` is the CPU oracle (a port of the
-same algorithm, oracle/) timed on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line.  `value` is whole-job configurations / wall time of the K timed steps (inputs resident in
+HBM).  Beside it, all timed with HIP events on the launch stream, median and min over >= 10 repetitions:
+  roofline              the validity step against HBM as the contract asks (56 B of q + 1 bit per configuration); the
+                        step is VALU-bound by construction, `valu_issue` prices it against that roof
+  end_to_end            the same step from HOST memory: H2D of q (pinned and pageable) + kernels + D2H of the mask words
+  edge_roofline         BASELINE config 3: E = 1e5 DiscreteConnector edges, resolution 0.01, 8-cube ring
+  records               BASELINE config 5: M = 10 071 samples, every pair's distance / contact points / normal / (P,7) row,
+                        on the primitive scene and on the mesh scene (compound-mesh collision shapes)
+  config4_shard         one GPU's share of config 4's 1e7 batch (1.25e6 q)
+  fk_roofline, fk_all_links_roofline, jacobian_roofline   the HBM-bound kernels of the path
+  cpu_baseline          the CPU oracle (a port of the same algorithm, oracle/) on this box's host cores, bounded sample
 """
 import argparse
 import json
@@ -27,7 +34,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6   # vector float64, FMA = 2 flop
+N_ROTATE = 5                   # distinct q batches in the timed loop
+
+
+def stats_ms(ms):
+    ms = sorted(float(x) for x in ms)
+    return {"median_ms": ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2]),
+            "min_ms": ms[0], "mean_ms": float(np.mean(ms)), "reps": len(ms)}
 
 
 def main():
@@ -35,9 +48,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1_000_000, help="configurations per GPU per step")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="configurations per GPU per step (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0, help="total configurations per step, split over the ranks (strong scaling; "
+                    "BASELINE config 4 is --global-batch 10000000)")
     ap.add_argument("--scene", default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline step (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the control flow)")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--sync-gather", action="store_true", help="N > 1: wait for every step's mask all-gather before the next step's kernels "
@@ -59,19 +75,23 @@ def main():
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from numbotics_amd.physics import World
+    from numbotics_amd.physics.world import _reset_worlds
     from numbotics_amd.scenes import build_scene, sample_q
     from numbotics_amd.parallel import shard_bounds, allgather_mask_words
+    from numbotics_amd.csrc.build import source_digest
 
     World()
     arm, chain, obstacles = build_scene(args.scene)
     sm, dev = arm._scene_device()
-    B = args.batch
-    total = B * world
+    strong = args.global_batch > 0
+    total = args.global_batch if strong else args.batch * world
     lo, hi = shard_bounds(total, world, rank)
-    # every rank draws the same global batch description; each keeps only its shard (seeded per shard)
-    q_host = sample_q(chain, hi - lo, seed=1 + rank)
-    q = torch.from_numpy(q_host).cuda()
-    n_words = (hi - lo + 63) // 64
+    B = hi - lo
+    # every rank keeps only its shard (seeded per shard and per rotation slot)
+    q_host = sample_q(chain, B, seed=1 + rank)
+    qs = [torch.from_numpy(q_host).cuda()] + [torch.from_numpy(sample_q(chain, B, seed=1 + rank + 1000 * i)).cuda() for i in range(1, N_ROTATE)]
+    q = qs[0]
+    n_words = (B + 63) // 64
     gathered = torch.zeros((world * n_words,), dtype=torch.int64, device="cuda") if world > 1 else None
     # N > 1: the all-gather of a step's packed mask (a latency-bound 125 KB-per-rank message) runs on RCCL's stream while the
     # next step's kernels run; two receive buffers, a buffer is waited for before it is reused and all of them before the
@@ -80,7 +100,6 @@ def main():
     bufs = [gathered, torch.zeros_like(gathered)] if overlap else None
     pending = [None, None]
     counter = [0]
-
     state = {"overlap": overlap}
 
     def gather(words):
@@ -106,14 +125,10 @@ def main():
                 pending[i].wait()
                 pending[i] = None
 
-    def step():
-        words = dev.validity(q, 0.0, packed=True)
+    for k in range(args.warmup):
+        words = dev.validity(qs[k % N_ROTATE], 0.0, packed=True)
         if world > 1:
             gather(words)
-        return words
-
-    for _ in range(args.warmup):
-        words = step()
     drain()
     torch.cuda.synchronize()
     if world > 1:
@@ -123,7 +138,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        words = dev.validity(q, 0.0, packed=True)
+        words = dev.validity(qs[k % N_ROTATE], 0.0, packed=True)
         ev[k][1].record()
         if world > 1:
             gather(words)
@@ -136,111 +151,226 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    step_ms = [a.elapsed_time(b) for a, b in ev]
+    kern = stats_ms(step_ms)
+    kern_ms = kern["mean_ms"]
+    last_q_host = q_host if (args.steps - 1) % N_ROTATE == 0 else sample_q(chain, B, seed=1 + rank + 1000 * ((args.steps - 1) % N_ROTATE))
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    def timed(fn, reps=10, warm=2):
+        """per-repetition HIP-event times (ms) on the launch stream"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        es = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in es:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return stats_ms([a.elapsed_time(b) for a, b in es])
+
     value = total * args.steps / elapsed
     # ---- parity spot check against the oracle (the checker, not the thing measured) -------------------
     from oracle.cpu_oracle import Oracle
     orc = Oracle(sm)
     w = words.cpu().numpy().view(np.uint64)
-    bits = ((w[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).reshape(-1)[:hi - lo]
-    sl = np.arange(0, hi - lo, max(1, (hi - lo) // 20000))
-    parity_ok = bool(np.array_equal(bits[sl], orc.validity(q_host[sl], 0.0, nthreads=8)))
+    bits = ((w[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).reshape(-1)[:B]
+    sl = np.arange(0, B, max(1, B // 20000))
+    parity_ok = bool(np.array_equal(bits[sl], orc.validity(last_q_host[sl], 0.0, nthreads=8)))
     coll_frac = float(bits.mean())
 
-    # ---- roofline of the dominant kernel (validity) ---------------------------------------------------
-    alg_bytes = (hi - lo) * (8.0 * chain.dof) + n_words * 8.0
+    # ---- roofline of the dominant kernels (the validity step) --------------------------------------------------
+    alg_bytes = B * (8.0 * chain.dof) + n_words * 8.0
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-    traffic, fk_traffic, traffic_src, valu = None, None, None, None
+    traffic, fk_traffic, traffic_src, valu, traffic_note = None, None, None, None, None
     import glob
+    digest = source_digest()
     side = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
     if side:
         # HBM bytes from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction) of this same
-        # command at batch 1e6; scaled to this run's batch.  bench.py cannot host the profiler itself.
+        # command at batch 1e6, scaled to this run's batch.  bench.py cannot host the profiler itself, so the counters come
+        # from a committed profile -- but ONLY of the kernel sources this run was built from (csrc_sha); anything else is stale
         with open(side[-1]) as f:
             tj = json.load(f)
-        scale = (hi - lo) / float(tj.get("batch", hi - lo))
-        traffic = tj["validity_step_hbm_bytes"] * scale
-        fk_traffic = tj["kernels"]["k_fk"]["hbm_bytes_corrected"] * scale
-        traffic_src = os.path.relpath(side[-1], ROOT)
-        valu = tj.get("sq")
-    roofline = {"bound": "hbm", "kernel": "k_broad + k_narrow (one nbk_validity_batch call)" if (hi - lo) >= 8192 else "k_validity",
+        if tj.get("csrc_sha") == digest:
+            scale = B / float(tj.get("batch", B))
+            traffic = tj["validity_step_hbm_bytes"] * scale
+            fk_traffic = tj["kernels"].get("k_fk", {}).get("hbm_bytes_corrected")
+            fk_traffic = None if fk_traffic is None else fk_traffic * scale
+            traffic_src = os.path.relpath(side[-1], ROOT)
+            valu = tj.get("sq")
+        else:
+            traffic_note = (f"{os.path.relpath(side[-1], ROOT)} was measured on kernel sources {tj.get('csrc_sha')}, this run is "
+                            f"{digest}: PMC figures withheld")
+    roofline = {"bound": "hbm", "kernel": "k_broad_f32 + k_narrow_bool (one nbk_validity_batch call)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kern_ms,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+                "kernel_ms": kern_ms, "kernel_ms_median": kern["median_ms"], "kernel_ms_min": kern["min_ms"], "reps": kern["reps"],
                 "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_config": 8.0 * chain.dof + 0.125,
                 "note": "VALU-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md",
-                "valu": valu}
+                "csrc_sha": digest, "valu": valu}
     if valu:
         # the roof that does bound the step: vector-ALU issue (256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at
         # 2.4 GHz).  Instruction counts per wave from the SQ pass of the profile the traffic comes from, time from this run.
         step_k = [k for k in ("k_broad_f32", "k_broad_reg", "k_broad", "k_narrow") if k in valu]
-        insts = sum(valu[k]["valu_insts_per_wave"] * valu[k]["waves"] for k in step_k) * scale
+        insts = sum(valu[k]["valu_insts_per_wave"] * valu[k]["waves"] for k in step_k) * (B / float(tj.get("batch", B)))
         peak = 1024 * 2.4e9 / 4.0
         roofline["valu_issue"] = {"bound": "valu", "achieved": insts / (kern_ms * 1e-3), "peak": peak, "unit": "wave-instructions/s",
                                   "frac": insts / (kern_ms * 1e-3) / peak, "wave_instructions_per_step": insts,
-                                  "wave_instructions_per_config": insts / (hi - lo), "kernels": step_k}
+                                  "wave_instructions_per_config": insts / B, "kernels": step_k}
 
-    # ---- the HBM-bound kernel of the path: pose-writing FK of one frame -------------------------------
-    T = arm.forward_kinematics(q, "tool_frame")
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    e0.record()
-    for _ in range(reps):
-        T = arm.forward_kinematics(q, "tool_frame")
-    e1.record()
-    torch.cuda.synchronize()
-    fk_ms = e0.elapsed_time(e1) / reps
-    fk_bytes = (hi - lo) * (8.0 * chain.dof + 128.0)
-    fk_gbs = fk_bytes / (fk_ms * 1e-3) / 1e9
-    fk_roofline = {"bound": "hbm", "kernel": "k_fk", "achieved": fk_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": fk_gbs / HBM_PEAK_GBS, "traffic": fk_traffic, "kernel_ms": fk_ms, "algorithmic_bytes": fk_bytes,
-                   "poses_per_s": (hi - lo) / (fk_ms * 1e-3), "algorithmic_bytes_per_config": 8.0 * chain.dof + 128.0}
+    out = {
+        "metric": "collision-checked configs/sec, Kinova 7-DoF + obstacles",
+        "value": value, "unit": "configs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Arm.in_collision, Kinova-like 7-DoF (build-authored kinova_cyl.urdf), scene {args.scene}: "
+                               f"{sm.n_pairs} primitive pairs ({sm.n_rshapes} robot shapes, {sm.n_wshapes} obstacle), "
+                               f"{B} q per GPU per step, threshold 0, packed bit mask; the timed loop rotates over {N_ROTATE} distinct "
+                               f"q batches ({N_ROTATE * B * 8 * chain.dof / 2**20:.0f} MiB)"
+                               + (", RCCL all-gather of mask words" if world > 1 else ""),
+                   "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
+                   "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if state["overlap"] else "serial")),
+                   "arithmetic": "float32 broadphase culls / certifies with a slack that only lets it decide what float64 would decide the "
+                                 "same way; every other verdict is computed in float64; the mask is bit-exact vs the CPU oracle on the sample"},
+        "roofline": roofline,
+        "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",
+        "parity_sample": int(sl.size),
+        "parity_note": "GPU vs this build's CPU oracle (oracle/); parity of collision values vs the reference's PyBullet is UNPINNED "
+                       "(third-party, absent, no reference fixture) -- FK / Jacobian / edge sampling are pinned by reference-generated golden vectors",
+    }
 
-    # ---- every link pose from one sweep (56 + 128 L bytes per configuration) ----------------
-    TA, link_names = arm.forward_kinematics_all(q)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(10):
-        TA, _ = arm.forward_kinematics_all(q)
-    e1.record()
-    torch.cuda.synchronize()
-    fa_ms = e0.elapsed_time(e1) / 10
-    L = len(link_names)
-    fa_bytes = (hi - lo) * (8.0 * chain.dof + 128.0 * L)
-    fk_all_roofline = {"bound": "hbm", "kernel": "k_fk_frames", "achieved": fa_bytes / (fa_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                       "unit": "GB/s", "frac": fa_bytes / (fa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": fa_ms,
-                       "algorithmic_bytes": fa_bytes, "link_frames": L, "poses_per_s": (hi - lo) * L / (fa_ms * 1e-3),
-                       "algorithmic_bytes_per_config": 8.0 * chain.dof + 128.0 * L}
-    del TA
+    if not args.no_extras:
+        # ---- end to end from host memory: H2D q + kernels + D2H mask words (PCIe inclusive; never `value`) ---------------
+        pin_q = torch.from_numpy(q_host).pin_memory()
+        pin_w = torch.empty((n_words,), dtype=torch.int64).pin_memory()
+        dq = torch.empty_like(q)
+        page_q = torch.from_numpy(q_host)
 
-    # ---- geometric Jacobian of the tool frame (56 in + 6 x dof x 8 out per configuration) --------
-    J = arm.jacobian(q, "tool_frame")
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(10):
-        J = arm.jacobian(q, "tool_frame")
-    e1.record()
-    torch.cuda.synchronize()
-    jac_ms = e0.elapsed_time(e1) / 10
-    jac_bytes = (hi - lo) * (8.0 * chain.dof + 48.0 * chain.dof)
-    jacobian_roofline = {"bound": "hbm", "kernel": "k_jacobian_reg", "achieved": jac_bytes / (jac_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": jac_bytes / (jac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": jac_ms,
-                         "algorithmic_bytes": jac_bytes, "jacobians_per_s": (hi - lo) / (jac_ms * 1e-3),
-                         "algorithmic_bytes_per_config": 56.0 * chain.dof}
-    del J
+        def e2e(src):
+            dq.copy_(src, non_blocking=True)
+            wds = dev.validity(dq, 0.0, packed=True)
+            pin_w.copy_(wds, non_blocking=True)
+        e_pin = timed(lambda: e2e(pin_q), reps=10)
+        e_page = timed(lambda: e2e(page_q), reps=10)
+        out["end_to_end"] = {"what": "H2D of q + nbk_validity_batch + D2H of the packed mask, per step", "batch": B,
+                             "pinned": dict(e_pin, configs_per_s=B / (e_pin["median_ms"] * 1e-3)),
+                             "pageable": dict(e_page, configs_per_s=B / (e_page["median_ms"] * 1e-3)),
+                             "h2d_bytes": B * 8.0 * chain.dof, "d2h_bytes": n_words * 8.0}
+        del pin_q, dq, page_q
+
+        # ---- the HBM-bound kernels of the path, rotating inputs ---------------------------------------------------------
+        it = [0]
+
+        def nxt():
+            it[0] += 1
+            return qs[it[0] % N_ROTATE]
+        fk = timed(lambda: arm.forward_kinematics(nxt(), "tool_frame"), reps=20)
+        fk_bytes = B * (8.0 * chain.dof + 128.0)
+        fk_gbs = fk_bytes / (fk["median_ms"] * 1e-3) / 1e9
+        out["fk_roofline"] = dict(fk, bound="hbm", kernel="k_fk", achieved=fk_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=fk_gbs / HBM_PEAK_GBS,
+                                  traffic=fk_traffic, kernel_ms=fk["median_ms"], algorithmic_bytes=fk_bytes,
+                                  poses_per_s=B / (fk["median_ms"] * 1e-3), algorithmic_bytes_per_config=8.0 * chain.dof + 128.0)
+        _, link_names = arm.forward_kinematics_all(q[:64])
+        L = len(link_names)
+        fa = timed(lambda: arm.forward_kinematics_all(nxt()), reps=10)
+        fa_bytes = B * (8.0 * chain.dof + 128.0 * L)
+        fa_gbs = fa_bytes / (fa["median_ms"] * 1e-3) / 1e9
+        out["fk_all_links_roofline"] = dict(fa, bound="hbm", kernel="k_fk_frames", achieved=fa_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                                            frac=fa_gbs / HBM_PEAK_GBS, traffic=None, kernel_ms=fa["median_ms"], algorithmic_bytes=fa_bytes,
+                                            link_frames=L, poses_per_s=B * L / (fa["median_ms"] * 1e-3),
+                                            algorithmic_bytes_per_config=8.0 * chain.dof + 128.0 * L)
+        jc = timed(lambda: arm.jacobian(nxt(), "tool_frame"), reps=10)
+        jac_bytes = B * (8.0 * chain.dof + 48.0 * chain.dof)
+        jac_gbs = jac_bytes / (jc["median_ms"] * 1e-3) / 1e9
+        out["jacobian_roofline"] = dict(jc, bound="hbm", kernel="k_jacobian_reg", achieved=jac_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=jac_gbs / HBM_PEAK_GBS, traffic=None, kernel_ms=jc["median_ms"], algorithmic_bytes=jac_bytes,
+                                        jacobians_per_s=B / (jc["median_ms"] * 1e-3), algorithmic_bytes_per_config=56.0 * chain.dof)
+
+        # ---- config 4's per-GPU shard: 1e7 / 8 = 1.25e6 q ----------------------------------------------------------------
+        if not strong and B == 1_000_000:
+            q4 = torch.from_numpy(sample_q(chain, 1_250_000, seed=4)).cuda()
+            c4 = timed(lambda: dev.validity(q4, 0.0, packed=True), reps=10)
+            out["config4_shard"] = dict(c4, what="one GPU's share of BASELINE config 4 (1e7 q over 8 GPUs): 1.25e6 q, packed mask; the full "
+                                        "config is `--gpus 8 --global-batch 10000000`", batch=1_250_000,
+                                        configs_per_s=1_250_000 / (c4["median_ms"] * 1e-3))
+            del q4
+        del qs[1:]
+
+        # ---- config 5: per-sample proximity records on M = 10 071 samples ---------------------------------------------------
+        M = 10071
+        rec = {"what": "BASELINE config 5 / SURVEY.md 8d C5: per sample every allowed pair's signed distance, contact points, normal "
+                       "(80 B) and (P, n_q) proximity-Jacobian row -- nbk_proximity_jacobian_batch -- and the 1e-6 tolerance mask", "samples": M}
+        q5 = torch.from_numpy(sample_q(chain, M, seed=31)).cuda()
+        r5 = timed(lambda: dev.proximity_jacobian(q5), reps=10)
+        m5 = timed(lambda: dev.validity(q5, 1e-6, packed=True), reps=10)
+        per_cfg = 8.0 * chain.dof + sm.n_pairs * (80.0 + 8.0 * chain.dof)
+        rec["primitive_scene"] = dict(r5, scene=args.scene, pairs=sm.n_pairs, bytes_per_config=per_cfg,
+                                      achieved_GBps=M * per_cfg / (r5["median_ms"] * 1e-3) / 1e9, samples_per_s=M / (r5["median_ms"] * 1e-3),
+                                      mask_median_ms=m5["median_ms"], mask_min_ms=m5["min_ms"])
+        # ---- config 3: E = 1e5 edges, resolution 0.01, 8-cube ring ------------------------------------------------------------
+        _reset_worlds()
+        World()
+        arm3, chain3, obs3 = build_scene("c3")
+        sm3, dev3 = arm3._scene_device()
+        E = 100_000
+        rng = np.random.default_rng(3)
+        lim = chain3.joint_limits
+        s_ = rng.uniform(lim[:, 0], lim[:, 1], (E, chain3.dof))
+        g_ = rng.uniform(lim[:, 0], lim[:, 1], (E, chain3.dof))
+        d_ = np.linalg.norm(g_ - s_, axis=1)
+        g_ = s_ + (g_ - s_) * np.minimum(1.0, rng.uniform(0.2, 1.0, E) * np.pi / d_)[:, None]     # |dq| <= pi = max_distance (_test_rrt.py:98)
+        ts, tg = torch.from_numpy(s_).cuda(), torch.from_numpy(g_).cuda()
+        ok, _, ns = dev3.edge_validity(ts, tg, 0.01, np.pi)
+        n_samples = int(ns.sum().item())
+        ed = timed(lambda: dev3.edge_validity(ts, tg, 0.01, np.pi), reps=10, warm=1)
+        sl_e = np.arange(0, E, 250)
+        okr = Oracle(sm3).edge_validity(s_[sl_e], g_[sl_e], 0.01, np.pi, nthreads=8)[0]
+        edge_parity = bool(np.array_equal(ok.cpu().numpy()[sl_e], okr))
+        eb = E * (16.0 * chain3.dof + 1.0)
+        out["edge_roofline"] = dict(ed, what="BASELINE config 3: DiscreteConnector.connect over E edges (end points U(limits), |dq| <= pi), resolution "
+                                    "0.01, 8 Cube(0.25) on a ring (SURVEY.md 8d C3): nbk_edge_validity_batch, asynchronous", edges=E, pairs=sm3.n_pairs,
+                                    checked_samples=n_samples, edges_per_s=E / (ed["median_ms"] * 1e-3),
+                                    checked_configs_per_s=n_samples / (ed["median_ms"] * 1e-3), bound="hbm", algorithmic_bytes=eb,
+                                    algorithmic_bytes_per_edge=16.0 * chain3.dof + 1.0, achieved=eb / (ed["median_ms"] * 1e-3) / 1e9,
+                                    peak=HBM_PEAK_GBS, unit="GB/s", frac=eb / (ed["median_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    valid_fraction=float(ok.float().mean().item()),
+                                    parity_vs_oracle=("bit-exact" if edge_parity else "MISMATCH") + f" on {sl_e.size} edges")
+        del ts, tg, dev3, arm3
+        # ---- config 5 on compound-mesh collision shapes -------------------------------------------------------------------------
+        _reset_worlds()
+        World()
+        arm5, chain5, obs5 = build_scene("c5m")
+        sm5, dev5 = arm5._scene_device()
+        q5h = sample_q(chain5, M, seed=31)
+        q5m = torch.from_numpy(q5h).cuda()
+        d5, w5, j5 = dev5.proximity_jacobian(q5m)
+        r5m = timed(lambda: dev5.proximity_jacobian(q5m), reps=10)
+        m5m = timed(lambda: dev5.validity(q5m, 1e-6, packed=True), reps=10)
+        orc5 = Oracle(sm5)
+        dr, wr, jr = orc5.proximity_jacobian(q5h[:200])
+        mesh_parity = bool(np.array_equal(d5[:200].cpu().numpy(), dr) and np.array_equal(w5[:200].cpu().numpy(), wr)
+                           and np.array_equal(j5[:200].cpu().numpy(), jr))
+        per_cfg5 = 8.0 * chain5.dof + sm5.n_pairs * (80.0 + 8.0 * chain5.dof)
+        rec["mesh_scene"] = dict(r5m, scene="c5m: mesh arm (10 hulls, one two-object compound link) among a rock, a five-object table, an STL "
+                                 "wedge and a cube", pairs=sm5.n_pairs, hulls=sm5.n_hulls, hull_vertices=int(len(sm5.hull_verts)),
+                                 bytes_per_config=per_cfg5, achieved_GBps=M * per_cfg5 / (r5m["median_ms"] * 1e-3) / 1e9,
+                                 samples_per_s=M / (r5m["median_ms"] * 1e-3), mask_median_ms=m5m["median_ms"], mask_min_ms=m5m["min_ms"],
+                                 parity_vs_oracle=("bit-exact" if mesh_parity else "MISMATCH") + " on 200 samples (distances, witnesses, rows)")
+        out["records"] = rec
+        if not (edge_parity and mesh_parity):
+            parity_ok = False
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample ---------------------
-    cpu = None
     if not args.no_cpu_baseline:
         # the box's CPU share for one GPU is 16 cores (gpurun guidance); never more threads than allowed CPUs
         cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
-        n_s = min(hi - lo, 1_000_000)
+        n_s = min(B, 1_000_000)
         t_start = time.perf_counter()
         reps_cpu = 0
         while True:
@@ -253,33 +383,18 @@ def main():
         n_1 = min(n_s, 100_000)
         orc.validity(q_host[:n_1], 0.0, nthreads=1)
         one_thread = n_1 / (time.perf_counter() - t1s)
-        cpu = {"value": n_s * reps_cpu / cpu_t, "unit": "configs/s", "cores": cores, "kind": "port",
-               "sample": f"{reps_cpu} x the first {n_s} configurations of rank 0's batch, oracle/nbk_oracle.c "
-                         f"orc_validity with {cores} pthreads (~{cpu_t * cores:.0f} core-seconds)",
-               "single_thread_value": one_thread}
+        out["cpu_baseline"] = {"value": n_s * reps_cpu / cpu_t, "unit": "configs/s", "cores": cores, "kind": "port",
+                               "sample": f"{reps_cpu} x the first {n_s} configurations of rank 0's batch, oracle/nbk_oracle.c "
+                                         f"orc_validity with {cores} pthreads (~{cpu_t * cores:.0f} core-seconds)",
+                               "single_thread_value": one_thread}
+    else:
+        out["cpu_baseline"] = None
 
-    out = {
-        "metric": "collision-checked configs/sec, Kinova 7-DoF + obstacles",
-        "value": value, "unit": "configs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"Arm.in_collision, Kinova-like 7-DoF (build-authored kinova_cyl.urdf), scene {args.scene}: "
-                               f"{sm.n_pairs} primitive pairs ({sm.n_rshapes} robot shapes, {sm.n_wshapes} obstacle), "
-                               f"{B} q per GPU per step, threshold 0, packed bit mask"
-                               + (", RCCL all-gather of mask words" if world > 1 else ""),
-                   "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
-                   "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if state["overlap"] else "serial")),
-                   "arithmetic": "every verdict is decided in float64 (bit-exact vs the CPU oracle); the broadphase culls in float32 with a slack that only lets it cull what float64 would"},
-        "roofline": roofline, "fk_roofline": fk_roofline, "fk_all_links_roofline": fk_all_roofline, "jacobian_roofline": jacobian_roofline,
-        "cpu_baseline": cpu,
-        "collision_fraction": coll_frac, "parity_vs_oracle": "bit-exact" if parity_ok else "MISMATCH",
-        "parity_sample": int(sl.size),
-    }
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
     if not parity_ok:
-        raise SystemExit("GPU mask differs from the oracle")
+        raise SystemExit("GPU results differ from the oracle")
 
 
 if __name__ == "__main__":

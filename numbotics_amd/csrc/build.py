@@ -17,6 +17,16 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
 
+def source_digest() -> str:
+    """sha256 (first 16 hex digits) of the kernel sources: profiles record it, bench.py refuses counters of another build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SOURCES:
+        with open(os.path.join(HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -31,6 +41,19 @@ def up_to_date():
     return all(os.path.getmtime(os.path.join(HERE, s)) <= t for s in SOURCES)
 
 
+ABLATE_LIB = os.path.join(HERE, "libnbk_ablate.so")
+
+
+def build_ablate(verbose: bool = False) -> str:
+    """The diagnostic build with the NBK_ABLATE switches compiled in (tools/ablate.py, tools/narrow_prof.py).  Never loaded by
+    the package: tools point numbotics_amd._lib.LIB_PATH at it themselves."""
+    cmd = [hipcc()] + FLAGS + ["-DNBK_ABLATE_BUILD", os.path.join(HERE, "nbk.hip"), "-o", ABLATE_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=HERE)
+    return ABLATE_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and up_to_date():
         return LIB
@@ -42,4 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--ablate" in sys.argv:
+        print(build_ablate(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

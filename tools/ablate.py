@@ -1,5 +1,8 @@
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
+from numbotics_amd.csrc import build as _b
+from numbotics_amd import _lib as _l
+_l.LIB_PATH = _b.build_ablate()          # the diagnostic build (-DNBK_ABLATE_BUILD): the product library has no ablation switches
 from numbotics_amd.physics import World
 from numbotics_amd.scenes import build_scene, sample_q
 World()

@@ -19,7 +19,10 @@ import json
 import os
 from collections import defaultdict
 
+import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from numbotics_amd.csrc.build import source_digest      # the json records which kernel sources the counters belong to
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9
 VALU_F64_CYCLES = 4          # one wave64 float64 VALU instruction occupies its SIMD for 4 cycles (16 lanes/cycle)
@@ -70,7 +73,7 @@ def main():
     out = {"command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
            "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (mean over dispatches); gfx950 correction per "
                     "MI355X_MICROARCH.md: wide coalesced reads report 1/2 -> fetch_bytes = 2*FETCH_SIZE*1024",
-           "kernels": {}, "batch": a.batch}
+           "kernels": {}, "batch": a.batch, "csrc_sha": source_digest()}
     for k in sorted(set(fetch or {}) & set(write or {})):
         fk, wk = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"])
         out["kernels"][k] = {"FETCH_SIZE_KiB": fk, "WRITE_SIZE_KiB": wk, "fetch_bytes_corrected": 2 * fk * 1024,
