@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libnbk.so")
-SOURCES = ["nbk.hip", "nbk_device.hpp", os.path.join("..", "..", "include", "nbk.h")]
+SOURCES = ["nbk.hip", "nbk_device.hpp", os.path.join("..", "..", "include", "nbk.h"), "build.py"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
 
