@@ -3183,17 +3183,19 @@ struct Options {
     long long f64_broad;            // NBK_F64_BROAD: the float64 register broadphase instead of the conservative float32 one
     long long jac_two_sweep;        // NBK_JAC_TWO_SWEEP: the general Jacobian kernel also for short paths
     long long closest_brute;        // NBK_CLOSEST_BRUTE: every pair instead of branch-and-bound
+    long long narrow_parts_max;     // NBK_NARROW_PARTS_MAX: cap of the narrowphase workgroups per sub-queue
 };
 static long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 static Options g_opt = {env_ll("NBK_TWO_KERNEL_MIN_B", 1), env_ll("NBK_EDGE_BATCH_MIN_E", 1), env_ll("NBK_NO_REG_BROAD", 0),
-                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0)};
+                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16)};
 
 // diagnostic (not part of include/nbk.h): set one of the switches above by name; returns NBK_ERR_INVALID for an unknown name
 extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
     if (name == nullptr) return NBK_ERR_INVALID;
     struct { const char* n; long long* v; } tab[] = {
         {"two_kernel_min_b", &g_opt.two_kernel_min_b}, {"edge_batch_min_e", &g_opt.edge_batch_min_e}, {"no_reg_broad", &g_opt.no_reg_broad},
-        {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute}};
+        {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute},
+        {"narrow_parts_max", &g_opt.narrow_parts_max}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) { *t.v = (long long)value; return NBK_OK; }
     return NBK_ERR_INVALID;
 }
@@ -3493,7 +3495,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const doub
         const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q;
         // workgroups per sub-queue: one 64-item chunk each at a few survivors per configuration; more chunks are strided over
         unsigned parts = 4u * nblk / NSUB;
-        parts = parts < 4u ? 4u : (parts > 32u ? 32u : parts);
+        { const unsigned pmax = g_opt.narrow_parts_max > 0 ? (unsigned)g_opt.narrow_parts_max : 16u; parts = parts < 4u ? 4u : parts; parts = parts > pmax ? pmax : parts; }
         if (!any_nonzero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero && !any_negative)
