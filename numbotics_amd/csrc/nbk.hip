@@ -38,6 +38,7 @@ struct DevModel {
     const int* joint_save;        // [J] slot to park this frame in, or -1
     const int* joint_shape_begin; // [J+2] robot shapes (in `order`) of frame k-1 are [begin[k], begin[k+1])
     const double* joint_rot;      // [J][27]
+    const int* joint_kind;        // [J] 0/1/2: revolute about that coordinate axis of the joint frame (known zeros in joint_rot), 3: general revolute, 4: prismatic
     const double* joint_trans;    // [J][3]
     const double* joint_slide;    // [J][3]
     const double* joint_axis;     // [J][3]
@@ -203,13 +204,52 @@ NBK_DEV bool row_nonfinite(const double* row, int n, int stride) {
     return bad;
 }
 
-// child frame of joint k (robots/helpers.py:43-55 restated with the host-made M0/M1/M2)
+// child frame of joint k (robots/helpers.py:43-55 restated with the host-made M0/M1/M2):
+//   L = M0 - cos(q) M1 + sin(q) M2 (each element fma(s, M2, fma(-c, M1, M0))),  tl = fma(q, slide, trans),  out = parent * (L, tl).
+// Joints whose axis is a coordinate axis of the joint frame (every joint of the usual URDFs) have known zeros in the tables:
+// column KZ of M1 and M2, and the two other columns of M0 (the host stores exact +0 there).  joint_kind[k] = KZ names that case and the
+// same formula is evaluated with literal zeros -- bit-identical (fma(x, y, +0.0) is what the table would give), but every
+// instruction now reads ONE scalar constant instead of two or three, so the v_mov's that fed the extra constants (40 % of the
+// VALU stream of k_fk) are gone and column KZ of L stays in scalar registers.  Prismatic joints: L = M0, all scalar.
+enum { JK_GENERIC = 3, JK_PRISMATIC = 4 };
+
+template <int KZ>
+NBK_DEV void joint_apply_axis(const double* M, const double* toff, const Xf& a, double qk, double s, double c, Xf& o) {
+    constexpr int U = (KZ + 1) % 3, V = (KZ + 2) % 3;
+    double Lu[3], Lv[3], tl[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Lu[r] = NBK_FMA(s, M[18 + 3 * r + U], NBK_FMA(-c, M[9 + 3 * r + U], 0.0));
+        Lv[r] = NBK_FMA(s, M[18 + 3 * r + V], NBK_FMA(-c, M[9 + 3 * r + V], 0.0));
+        tl[r] = NBK_FMA(qk, 0.0, toff[r]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a0 = a.R[3 * i], a1 = a.R[3 * i + 1], a2 = a.R[3 * i + 2];
+        o.R[3 * i + U] = NBK_FMA(a2, Lu[2], NBK_FMA(a1, Lu[1], a0 * Lu[0]));
+        o.R[3 * i + V] = NBK_FMA(a2, Lv[2], NBK_FMA(a1, Lv[1], a0 * Lv[0]));
+        o.R[3 * i + KZ] = NBK_FMA(a2, M[6 + KZ], NBK_FMA(a1, M[3 + KZ], a0 * M[KZ]));
+        o.t[i] = NBK_FMA(a2, tl[2], NBK_FMA(a1, tl[1], NBK_FMA(a0, tl[0], a.t[i])));
+    }
+}
+
 NBK_DEV void joint_apply(const DevModel& m, int k, const Xf& parent, double qk, Xf& out) {
     const double* M = m.joint_rot + 27 * k;
     const double* toff = m.joint_trans + 3 * k;
     const double* sl = m.joint_slide + 3 * k;
+    const int kind = m.joint_kind[k];                  // wave-uniform: scalar branches
+    if (kind == JK_PRISMATIC) {
+        double tl[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tl[i] = NBK_FMA(qk, sl[i], toff[i]);
+        xf_mul(parent, M, tl, out);                    // L = M0 (s = c = 0 and M1 = M2 = 0 in the general formula)
+        return;
+    }
     double s = 0.0, c = 0.0;
-    if (m.joint_type[k] == NBK_REVOLUTE) nbk_sincos(qk, s, c);
+    nbk_sincos(qk, s, c);
+    if (kind == 0) { joint_apply_axis<0>(M, toff, parent, qk, s, c, out); return; }
+    if (kind == 1) { joint_apply_axis<1>(M, toff, parent, qk, s, c, out); return; }
+    if (kind == 2) { joint_apply_axis<2>(M, toff, parent, qk, s, c, out); return; }
     double L[9], tl[3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) L[e] = NBK_FMA(s, M[18 + e], NBK_FMA(-c, M[9 + e], M[e]));
@@ -1709,12 +1749,37 @@ NBK_DEV void sincos_f(float x, float& s, float& c) {
     c = ((n + 1) & 2) ? -c0 : c0;
 }
 
+template <int KZ>
+NBK_DEV void joint_apply_axis_f(const float* M, const float* toff, const XfF& P, float s, float c, XfF& o) {
+    constexpr int U = (KZ + 1) % 3, V = (KZ + 2) % 3;
+    float Lu[3], Lv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Lu[r] = __builtin_fmaf(s, M[18 + 3 * r + U], -c * M[9 + 3 * r + U]);
+        Lv[r] = __builtin_fmaf(s, M[18 + 3 * r + V], -c * M[9 + 3 * r + V]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float a0 = P.R[3 * i], a1 = P.R[3 * i + 1], a2 = P.R[3 * i + 2];
+        o.R[3 * i + U] = __builtin_fmaf(a2, Lu[2], __builtin_fmaf(a1, Lu[1], a0 * Lu[0]));
+        o.R[3 * i + V] = __builtin_fmaf(a2, Lv[2], __builtin_fmaf(a1, Lv[1], a0 * Lv[0]));
+        o.R[3 * i + KZ] = __builtin_fmaf(a2, M[6 + KZ], __builtin_fmaf(a1, M[3 + KZ], a0 * M[KZ]));
+        o.t[i] = __builtin_fmaf(a2, toff[2], __builtin_fmaf(a1, toff[1], __builtin_fmaf(a0, toff[0], P.t[i])));
+    }
+}
+
+// the float32 sweep of the conservative broadphase (its error is covered by the slack, so nothing here has to match anything bit for
+// bit): same case split as joint_apply
 NBK_DEV void joint_apply_f(const DevModel& m, int k, const XfF& P, float qk, XfF& o) {
     const float* M = m.f_tab + 27 * k;
     const float* toff = m.f_tab + m.f_trans + 3 * k;
     const float* sl = m.f_tab + m.f_slide + 3 * k;
+    const int kind = m.joint_kind[k];
     float s = 0.0f, c = 0.0f;
-    if (m.joint_type[k] == NBK_REVOLUTE) sincos_f(qk, s, c);
+    if (kind != JK_PRISMATIC) sincos_f(qk, s, c);
+    if (kind == 0) { joint_apply_axis_f<0>(M, toff, P, s, c, o); return; }
+    if (kind == 1) { joint_apply_axis_f<1>(M, toff, P, s, c, o); return; }
+    if (kind == 2) { joint_apply_axis_f<2>(M, toff, P, s, c, o); return; }
     float L[9], tl[3];
 #pragma unroll
     for (int e = 0; e < 9; ++e) L[e] = __builtin_fmaf(s, M[18 + e], __builtin_fmaf(-c, M[9 + e], M[e]));
@@ -2920,8 +2985,32 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.jl = B.add(load.data(), sizeof(int) * J);
     o.js = B.add(save.data(), sizeof(int) * J);
     o.jb = B.add(begin.data(), sizeof(int) * (J + 2));
-    o.jr = B.add(d->joint_rot, sizeof(double) * 27 * J);
-    o.jtr = B.add(d->joint_trans, sizeof(double) * 3 * J);
+    // exact zeros of the joint tables are stored as +0 (so that a literal 0.0 in the axis-aligned fast paths is the same operand),
+    // and every joint is classified: which coordinate axis of the joint frame it turns about, if any
+    std::vector<double> jrot(d->joint_rot, d->joint_rot + 27 * (size_t)J), jtrans(d->joint_trans, d->joint_trans + 3 * (size_t)J);
+    for (double& v : jrot) v += 0.0;
+    for (double& v : jtrans) v += 0.0;
+    std::vector<int> joint_kind(J > 0 ? J : 1, JK_GENERIC);
+    for (int k = 0; k < J; ++k) {
+        const double* M = &jrot[27 * (size_t)k];
+        if (d->joint_type[k] == NBK_PRISMATIC) {
+            bool zero = true;
+            for (int e = 9; e < 27; ++e) zero = zero && M[e] == 0.0;
+            if (!zero) { delete M; snprintf(g_err, sizeof(g_err), "prismatic joint %d: M1 / M2 of joint_rot must be zero", k); return NBK_ERR_INVALID; }
+            joint_kind[k] = JK_PRISMATIC;
+            continue;
+        }
+        for (int kz = 0; kz < 3; ++kz) {
+            const int u = (kz + 1) % 3, v = (kz + 2) % 3;
+            bool ok = d->joint_slide[3 * k] == 0.0 && d->joint_slide[3 * k + 1] == 0.0 && d->joint_slide[3 * k + 2] == 0.0;
+            for (int r = 0; r < 3; ++r)
+                ok = ok && M[9 + 3 * r + kz] == 0.0 && M[18 + 3 * r + kz] == 0.0 && M[3 * r + u] == 0.0 && M[3 * r + v] == 0.0;
+            if (ok) { joint_kind[k] = kz; break; }
+        }
+    }
+    o.jr = B.add(jrot.data(), sizeof(double) * 27 * J);
+    const size_t o_jk = B.add(joint_kind.data(), sizeof(int) * J);
+    o.jtr = B.add(jtrans.data(), sizeof(double) * 3 * J);
     o.jsl = B.add(d->joint_slide, sizeof(double) * 3 * J);
     o.jax = B.add(d->joint_axis, sizeof(double) * 3 * J);
     o.bp = B.add(d->base_pose, sizeof(double) * 12);
@@ -3071,6 +3160,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.joint_save = reinterpret_cast<const int*>(base + o.js);
     m.joint_shape_begin = reinterpret_cast<const int*>(base + o.jb);
     m.joint_rot = reinterpret_cast<const double*>(base + o.jr);
+    m.joint_kind = reinterpret_cast<const int*>(base + o_jk);
     m.joint_trans = reinterpret_cast<const double*>(base + o.jtr);
     m.joint_slide = reinterpret_cast<const double*>(base + o.jsl);
     m.joint_axis = reinterpret_cast<const double*>(base + o.jax);

@@ -122,6 +122,9 @@ def compile_kinematics(chain) -> KinematicModel:
         else:
             rot[k, 0:9] = R.reshape(9)
             slide[k] = R @ a
+    # exact zeros are stored as +0.0: the device evaluates axis-aligned joints with literal zeros in place of the table entries that
+    # are zero by construction (csrc/nbk.hip joint_apply), and x + 0.0 turns a -0.0 into the +0.0 that literal is
+    rot, trans, slide = rot + 0.0, trans + 0.0, slide + 0.0
     km = KinematicModel(
         n_q=chain.dof,
         joint_parent=np.array(parents, dtype=np.int32).reshape(J),

@@ -31,6 +31,7 @@ def kin_from_sequence(offsets, axes, types, idxs, base, n_q, trailing=None):
             rot[k, 18:27] = (R @ _skew(ax[k])).ravel()
         else:
             rot[k, 0:9] = R.ravel(); slide[k] = R @ ax[k]
+    rot, trans, slide = rot + 0.0, trans + 0.0, slide + 0.0          # exact zeros as +0.0, like compile_kinematics
     km = KinematicModel(
         n_q=n_q, joint_parent=np.arange(-1, J - 1, dtype=np.int32), joint_type=np.array(ty, dtype=np.int32),
         joint_qidx=np.array(qi, dtype=np.int32), joint_offset=np.array([_T34(m) for m in merged]).reshape(J, 12),
