@@ -102,6 +102,8 @@ struct EdgeSrc {
     const unsigned long long* total;     // edge mode: device address of the sample count (known only on the device: the launch
                                          // covers the scratch's capacity, blocks beyond the count exit at once)
     long long b0;                        // first configuration of this tile within the flat batch
+    unsigned char* ovf;                  // [blocks of the tile] set by a block whose items did not fit their sub-queue (queues are sized
+                                         // for a budget, not for the worst case): k_validity_redo re-decides that block without a queue
 };
 // configurations this launch really has: the tile size B, or what is left of the device-side sample count
 NBK_DEV int64_t effective_batch(const EdgeSrc& es, int64_t B) {
@@ -138,6 +140,10 @@ struct nbk_model {
     int n_q;
     int n_joints;
     int cls_count[4];          // pairs per kind class; cls_groups (in d) sub-queues serve each
+    // per pair, in broadphase order: what the per-call static reach test (k_prepare_f32) needs, so that the host can count the
+    // pairs a call can produce items for at ITS threshold and size queues / tiles for those instead of for every pair
+    std::vector<double> h_static, h_m0, h_m1;
+    std::vector<int> h_cat, h_cls;
     std::vector<int> h_joint_qidx, h_joint_type;   // host copies for make_path
     std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
@@ -172,6 +178,14 @@ static int hip_fail(hipError_t e, const char* what) {
 constexpr int WAVE = 64;
 
 NBK_DEV int core_rows(int kind) { return kind == K_POINT ? 3 : ((kind == K_BOX || kind == K_HULL) ? 12 : 6); }
+
+// sample t of flat-batch entry `mp` = (edge << 32 | sample index): i * step for i < n, T_f for the last sample
+NBK_DEV double edge_t(const EdgeSrc& es, unsigned long long mp, unsigned& e_out) {
+    const unsigned e = (unsigned)(mp >> 32), i = (unsigned)mp;
+    const double* pl = es.plan + 3 * (size_t)e;
+    e_out = e;
+    return ((double)i < pl[2]) ? (double)i * pl[0] : pl[1];
+}
 
 // ---- q staging: rows [B][n_q] -> LDS [n_q][64] ---------------------------------------------------
 // The block's slab of q is contiguous (64*n_q doubles); it is read with 16-byte loads where the slab is
@@ -1130,6 +1144,49 @@ __global__ __launch_bounds__(64) void k_validity(DevModel m, const double* __res
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
 }
 
+// The queues of the broadphase + narrowphase pipeline are sized for a BUDGET (1 GiB), not for the worst case of every pair of every
+// configuration surviving.  A block whose items did not fit marks itself (EdgeSrc::ovf); this kernel then decides the marked blocks
+// the queue-less way -- every pair of the 64 configurations, as k_validity does -- and ORs the verdicts into the mask.  Items the
+// block did get into the queue were decided by the narrowphase as well: same verdicts twice.  Unmarked blocks exit at once; a
+// marked block clears its mark.
+__global__ __launch_bounds__(64) void k_validity_redo(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
+                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes) {
+    extern __shared__ double lds[];
+    if (es.ovf[blockIdx.x] == 0) return;
+    const int lane = threadIdx.x;
+    if (lane == 0) es.ovf[blockIdx.x] = 0;
+    const int64_t base = (int64_t)blockIdx.x * WAVE;
+    const int64_t Beff = effective_batch(es, B);
+    if (base >= Beff) return;
+    double* lds_q = lds;
+    double* lds_s = lds_q + WAVE * m.n_q;
+    double* lds_fr = lds_s + WAVE * m.shape_rows;
+    unsigned* lds_x = reinterpret_cast<unsigned*>(lds_fr + WAVE * 12 * m.frame_slots);
+    const bool active = (base + lane) < Beff;
+    if (es.map != nullptr) {
+        const int nq = m.n_q;
+        if (active) {
+            unsigned e;
+            const double t = edge_t(es, es.map[base + lane], e);
+            const double omt = 1.0 - t;
+            const double* sp = es.starts + (size_t)e * nq;
+            const double* gp = es.goals + (size_t)e * nq;
+            for (int j = 0; j < nq; ++j) { const double a = omt * sp[j]; const double bb = t * gp[j]; lds_q[j * WAVE + lane] = a + bb; }
+        } else {
+            for (int j = 0; j < nq; ++j) lds_q[j * WAVE + lane] = 0.0;
+        }
+        __syncthreads();
+    } else {
+        stage_q(q, base, Beff, m.n_q, lds_s, lds_q, lane);
+    }
+    sweep_and_park(m, lds_q, lds_s, lds_fr, lane);
+    const bool bad = row_nonfinite(lds_q + lane, m.n_q, WAVE);
+    const bool hit = wave_collides(m, lds_s, lds_x, lane, thr, active) || bad;
+    const uint64_t word = __builtin_amdgcn_ballot_w64(hit && active);
+    if (mask_bits != nullptr && lane == 0 && word != 0ull) atomicOr(reinterpret_cast<unsigned long long*>(mask_bits) + blockIdx.x, (unsigned long long)word);
+    if (mask_bytes != nullptr && active && hit) mask_bytes[base + lane] = 1;
+}
+
 // ==== two-kernel validity for large batches ===========================================================
 // k_broad : one configuration per lane.  Sweeps the tree keeping ONLY the primitive centres (3 LDS rows per
 //           shape, so several waves fit a CU), runs the bounding-sphere test of every pair and appends the
@@ -1158,7 +1215,7 @@ constexpr int CNT_STRIDE = 16;          // one 128-byte line per counter
 // class c owns cls_groups[c] of the NSUB sub-queues (in proportion to its pairs), a block appends to the (block % groups)-th.  The chunks k_narrow takes are then kind-homogeneous -- one core layout, one
 // support routine per side -- which is worth 10 % of its time; one atomicAdd per class present, issued together by lanes 0-3.
 NBK_DEV void flush_items(const DevModel& m, unsigned* lds_queue, int qn, int64_t base_cfg, unsigned long long* q_count,
-                         unsigned long long* q_items, unsigned long long cap_sub, int lane) {
+                         unsigned long long* q_items, unsigned long long cap_sub, int lane, unsigned char* ovf) {
     __syncthreads();
     for (int i0 = 0; i0 < qn; i0 += WAVE) {
         const int i = i0 + lane;
@@ -1182,6 +1239,7 @@ NBK_DEV void flush_items(const DevModel& m, unsigned* lds_queue, int qn, int64_t
             const unsigned sub = (unsigned)(m.cls_base[cls] + (int)(blockIdx.x % (unsigned)m.cls_groups[cls]));
             const unsigned long long b = (unsigned long long)(base_cfg + (it & 63u));
             if (slot < cap_sub) q_items[(unsigned long long)sub * cap_sub + slot] = (b << 20) | (unsigned long long)(it >> 6);
+            else if (ovf != nullptr) ovf[blockIdx.x] = 1;          // the sub-queue is full: this block is re-decided without a queue
         }
     }
     __syncthreads();
@@ -1189,8 +1247,9 @@ NBK_DEV void flush_items(const DevModel& m, unsigned* lds_queue, int qn, int64_t
 
 // the NSUB queue counters are cleared by a kernel of our own: a hipMemsetAsync node did not reliably clear them
 // when the call was replayed from a captured hipGraph (ROCm 7.2), a plain kernel node does
-__global__ void k_zero_counters(unsigned long long* __restrict__ q_count) {
+__global__ void k_zero_counters(unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ flags, int flag_words) {
     q_count[threadIdx.x * CNT_STRIDE] = 0ull;
+    for (int i = threadIdx.x; i < flag_words; i += NSUB) flags[i] = 0ull;
 }
 
 // Per-call tables of the float32 broadphase, built once per launch sequence by one workgroup (instead of by every wave
@@ -1203,10 +1262,11 @@ __global__ void k_zero_counters(unsigned long long* __restrict__ q_count) {
 //               two shapes overlap => the pair collides, whatever the narrowphase would say in more digits; planes: thr + inA
 //   wcin [W*16] float  world boxes: (thr + inA + mBox - f_e2max)^2 against the centre's squared distance to the (core) box
 //   rptri[128]  int    sorted pair index of robot-robot slot (a,b) at its triangular index b(b-1)/2 + a
-NBK_DEV size_t ftab_entries(int W) { return 3 * 256 + 128 + 5 * (size_t)W * 16 + 32; }
+//   wlist[W], n_reach  int   the world shapes some robot shape can reach at this threshold, ascending; the world loop visits only those
+NBK_DEV size_t ftab_entries(int W) { return 3 * 256 + 128 + 5 * (size_t)W * 16 + 32 + (size_t)W + 16; }
 struct FTab {
     const float *rkey, *rcert, *wkey, *wtc, *wcert, *wcin, *rho;
-    const int *rp, *rptri, *wp;
+    const int *rp, *rptri, *wp, *wlist, *n_reach;
 };
 NBK_DEV FTab ftab_view(const float* tab, int W) {
     FTab t;
@@ -1215,13 +1275,16 @@ NBK_DEV FTab ftab_view(const float* tab, int W) {
     t.rptri = reinterpret_cast<const int*>(tab + 768);
     t.wkey = tab + 896; t.wtc = t.wkey + w16; t.wp = reinterpret_cast<const int*>(t.wtc + w16);
     t.wcert = t.wtc + 2 * w16; t.wcin = t.wcert + w16; t.rho = t.wcin + w16;
+    t.n_reach = reinterpret_cast<const int*>(t.rho + 32); t.wlist = t.n_reach + 16;
     return t;
 }
 
-__global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, unsigned long long* __restrict__ q_count, int n_sets, float* __restrict__ tab) {
+__global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, unsigned long long* __restrict__ q_count, int n_sets, float* __restrict__ tab,
+                                                     unsigned long long* __restrict__ flags, int flag_words) {
     const int t = threadIdx.x;
     const int W = m.n_wshapes;
     for (int s = 0; s < n_sets; ++s) q_count[((size_t)s * NSUB + t) * CNT_STRIDE] = 0ull;
+    for (int i = t; i < flag_words; i += 256) flags[i] = 0ull;           // overflow marks of the tile's blocks
     const FTab v = ftab_view(tab, W);
     float* rkey = const_cast<float*>(v.rkey); float* rcert = const_cast<float*>(v.rcert);
     int* rp = const_cast<int*>(v.rp); int* rptri = const_cast<int*>(v.rptri);
@@ -1279,6 +1342,28 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
             wp[w * 16 + a] = p;
         }
     }
+    // ---- the world shapes that are still somebody's pair, in ascending order ---------------------------------------------
+    __shared__ int s_cnt[4];
+    __shared__ int s_run;
+    if (t == 0) s_run = 0;
+    __syncthreads();                       // (also orders the wp[] writes above before the reads below)
+    int* wlist = const_cast<int*>(v.wlist);
+    for (int w0 = 0; w0 < W; w0 += 256) {
+        const int w = w0 + t;
+        bool reach = false;
+        if (w < W) for (int a = 0; a < 16; ++a) reach = reach || (wp[w * 16 + a] >= 0);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(reach);
+        const int wave = t >> 6;
+        if ((t & 63) == 0) s_cnt[wave] = __builtin_popcountll(bal);
+        __syncthreads();
+        int off = s_run;
+        for (int i = 0; i < wave; ++i) off += s_cnt[i];
+        if (reach) wlist[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = w;
+        __syncthreads();
+        if (t == 0) s_run += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        __syncthreads();
+    }
+    if (t == 0) *const_cast<int*>(v.n_reach) = s_run;
 }
 
 // LDS: raw q slab [64*n_q] | saved frames [12*slots][64] | centres [3*S][64] | pair constants [P][4] |
@@ -1289,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
 // and is a straight line per category.  Survivors are collected as one bit per (lane, pair) and turned into
 // queue items 64 pairs at a time.
 NBK_DEV void enqueue_bits(const DevModel& m, unsigned long long bits, int jbase, const double* lds_pc, unsigned* lds_queue, int& qn, int lane,
-                          int64_t base, unsigned long long* q_count, unsigned long long* q_items, unsigned long long cap) {
+                          int64_t base, unsigned long long* q_count, unsigned long long* q_items, unsigned long long cap, const EdgeSrc& es) {
     while (true) {
         const bool has = bits != 0ull;
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(has);
@@ -1303,16 +1388,10 @@ NBK_DEV void enqueue_bits(const DevModel& m, unsigned long long bits, int jbase,
             lds_queue[pos] = (p << 6) | (unsigned)lane;
         }
         qn += __builtin_popcountll(bal);
-        if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+        if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }
     }
 }
 
-NBK_DEV double edge_t(const EdgeSrc& es, unsigned long long mp, unsigned& e_out) {
-    const unsigned e = (unsigned)(mp >> 32), i = (unsigned)mp;
-    const double* pl = es.plan + 3 * (size_t)e;
-    e_out = e;
-    return ((double)i < pl[2]) ? (double)i * pl[0] : pl[1];
-}
 
 __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
@@ -1483,11 +1562,11 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
                 }
             }
             if (!active || hit || (NBK_DBG(m) & 4)) bits = 0ull;
-            enqueue_bits(m, bits, j0 + c0, lds_pc, lds_queue, qn, lane, base, q_count, q_items, cap);
+            enqueue_bits(m, bits, j0 + c0, lds_pc, lds_queue, qn, lane, base, q_count, q_items, cap, es);
         }
         j0 += ncat;
     }
-    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane);
+    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf);
     // the mask starts from the hits certified here; k_narrow ORs the rest in
     const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
@@ -1648,7 +1727,7 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
                     lds_queue[pos] = (p << 6) | (unsigned)lane;
                 }
                 qn += __builtin_popcountll(bal);
-                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }
             }
         }
     }
@@ -1710,10 +1789,10 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
                 lds_queue[pos] = (p << 6) | (unsigned)lane;
             }
             qn += __builtin_popcountll(bal);
-            if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }
         }
     }
-    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane);
+    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf);
     const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
@@ -1904,7 +1983,9 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     const bool cert_ok = e2 <= m.f_e2max;
     bool certh = false;
     int qn = 0;
-    for (int w = 0; w < W; ++w) {
+    const int n_reach = *ft.n_reach;
+    for (int wi = 0; wi < n_reach; ++wi) {
+        const int w = ft.wlist[wi];                 // only the world shapes within somebody's reach at this threshold
         const float* wc = m.f_tab + m.f_wc + 18 * w;
         const int wk = m.ws_kind[w];
         unsigned long long bits = 0ull;
@@ -1984,7 +2065,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 lds_queue[pos] = (p << 6) | (unsigned)lane;
             }
             qn += __builtin_popcountll(bal);
-            if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+            if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }
         }
     }
     if (m.bq_count[1] > 0) {
@@ -2014,11 +2095,11 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                     lds_queue[pos] = (p << 6) | (unsigned)lane;
                 }
                 qn += __builtin_popcountll(bal);
-                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane); qn = 0; }
+                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }
             }
         }
     }
-    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane);
+    if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf);
     const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
@@ -3213,6 +3294,13 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     M->h_joint_type.assign(d->joint_type, d->joint_type + J);
     M->margins_zero = margins_zero;
     for (int c = 0; c < 4; ++c) M->cls_count[c] = cls_count[c];
+    M->h_static = bq_static; M->h_static.resize(P > 0 ? P : 0);
+    M->h_m0.resize(P); M->h_m1.resize(P); M->h_cat.resize(P); M->h_cls.resize(P);
+    for (int j = 0; j < P; ++j) {
+        const int i = bq_tab[4 * j + 2];
+        M->h_m0[j] = vp_cst[4 * (size_t)i]; M->h_m1[j] = vp_cst[4 * (size_t)i + 1];
+        M->h_cat[j] = bq_tab[4 * j + 3]; M->h_cls[j] = vp_cls[i];
+    }
     M->gjk_margins = gjk_margins;
     M->lds_broad_ok = lds_broad_ok;
     M->parked_ok = parked_ok;
@@ -3274,10 +3362,12 @@ struct Options {
     long long jac_two_sweep;        // NBK_JAC_TWO_SWEEP: the general Jacobian kernel also for short paths
     long long closest_brute;        // NBK_CLOSEST_BRUTE: every pair instead of branch-and-bound
     long long narrow_parts_max;     // NBK_NARROW_PARTS_MAX: cap of the narrowphase workgroups per sub-queue
+    long long queue_budget;         // NBK_QUEUE_BUDGET: bytes the item queues of one tile may take (default 1 GiB); tests shrink it to force
+                                    // the overflow path (k_validity_redo)
 };
 static long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 static Options g_opt = {env_ll("NBK_TWO_KERNEL_MIN_B", 1), env_ll("NBK_EDGE_BATCH_MIN_E", 1), env_ll("NBK_NO_REG_BROAD", 0),
-                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16)};
+                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_QUEUE_BUDGET", 1ll << 30)};
 
 // diagnostic (not part of include/nbk.h): set one of the switches above by name; returns NBK_ERR_INVALID for an unknown name
 extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
@@ -3285,7 +3375,7 @@ extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
     struct { const char* n; long long* v; } tab[] = {
         {"two_kernel_min_b", &g_opt.two_kernel_min_b}, {"edge_batch_min_e", &g_opt.edge_batch_min_e}, {"no_reg_broad", &g_opt.no_reg_broad},
         {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute},
-        {"narrow_parts_max", &g_opt.narrow_parts_max}};
+        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) { *t.v = (long long)value; return NBK_OK; }
     return NBK_ERR_INVALID;
 }
@@ -3444,11 +3534,14 @@ static inline size_t collide_lds(const nbk_model* m) {
 
 // ---- validity: fused kernel for small batches, broadphase + compacted narrowphase for large ones -------
 static const size_t WS_MAX_BYTES = size_t(1) << 30;
+static const int64_t TILE_MAX = int64_t(1) << 22;               // configurations per queue tile at most (65 536 blocks)
+static const size_t WS_FLAGS = (size_t)(TILE_MAX / WAVE);       // one overflow mark per block of a tile
 static const size_t WS_COUNTER_SET = NSUB * CNT_STRIDE * 8;    // NSUB counters, one cache line each
 static const size_t WS_COUNTERS = 2 * WS_COUNTER_SET;          // two sets (see StreamWs::epoch)
-static inline size_t ws_header(const nbk_model* m) {           // counters | per-call float32 broadphase tables
-    return (WS_COUNTERS + 4 * (3 * 256 + 128 + 5 * (size_t)m->d.n_wshapes * 16 + 32) + 255) & ~size_t(255);
+static inline size_t ws_tables(const nbk_model* m) {           // counters | per-call float32 broadphase tables
+    return (WS_COUNTERS + 4 * (3 * 256 + 128 + 5 * (size_t)m->d.n_wshapes * 16 + 32 + (size_t)m->d.n_wshapes + 16) + 255) & ~size_t(255);
 }
+static inline size_t ws_header(const nbk_model* m) { return ws_tables(m) + WS_FLAGS; }      // ... | overflow marks | items follow
 
 static inline size_t broad_lds(const nbk_model* m) {
     const size_t qrows = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
@@ -3457,31 +3550,60 @@ static inline size_t broad_lds(const nbk_model* m) {
 
 // capacity (items) of one sub-queue for a tile of nblk 64-configuration blocks: the blocks that feed it times 64 times
 // the pairs of its class, maximised over the classes (all sub-queues get the same stride)
-static inline unsigned long long sub_queue_cap(const nbk_model* m, unsigned long long nblk) {
+struct PairCounts { int n[4]; };      // pairs per kind class that can produce queue items
+static inline PairCounts all_pairs(const nbk_model* m) { PairCounts c; for (int i = 0; i < 4; ++i) c.n[i] = m->cls_count[i]; return c; }
+// the pairs the static reach test leaves at this threshold (the very test k_prepare_f32 applies: a pair it drops can never pass
+// the bounding-sphere test of any broadphase, so it can never own a queue item)
+static inline PairCounts reachable_pairs(const nbk_model* m, double thr) {
+    PairCounts c = {{0, 0, 0, 0}};
+    const size_t P = m->h_cat.size();
+    for (size_t j = 0; j < P; ++j) {
+        const int cat = m->h_cat[j];
+        if (cat != 1) {
+            const double sl = m->h_static[j];
+            const double tcut = cat == 0 ? thr + m->h_m0[j] : (thr + m->h_m0[j]) + m->h_m1[j];
+            if (sl - 1e-9 * (1.0 + fabs(sl)) >= tcut) continue;
+        }
+        c.n[m->h_cls[j]] += 1;
+    }
+    return c;
+}
+static inline unsigned long long sub_queue_cap(const nbk_model* m, const PairCounts& pc, unsigned long long nblk) {
     unsigned long long cap = WAVE;
     for (int c = 0; c < 4; ++c) {
-        if (m->cls_count[c] == 0) continue;
+        if (pc.n[c] == 0) continue;
         const unsigned long long g = (unsigned long long)m->d.cls_groups[c];
-        const unsigned long long v = ((nblk + g - 1) / g) * WAVE * (unsigned long long)m->cls_count[c];
+        const unsigned long long v = ((nblk + g - 1) / g) * WAVE * (unsigned long long)pc.n[c];
         if (v > cap) cap = v;
     }
     return cap;
 }
 
-// configurations per tile such that the worst-case queue (every pair of every configuration) fits WS_MAX_BYTES
-static inline int64_t tile_configs(const nbk_model* m, int64_t B) {
-    // worst-case queue bytes per configuration: NSUB sub-queues of the stride the fullest class needs
+// Queue sizing.  Robots that fit the LDS-parked layout (the queue-less kernel can re-decide a block): one tile of up to TILE_MAX
+// configurations, every sub-queue as large as the worst case needs but at most its share of WS_MAX_BYTES -- blocks whose items do
+// not fit are re-decided by k_validity_redo.  Larger robots: tiles small enough for the worst case (every pair of every
+// configuration), as nothing can catch an overflow for them.
+static inline int64_t tile_configs(const nbk_model* m, const PairCounts& pc, int64_t B) {
+    const int64_t Bp = ((B + WAVE - 1) / WAVE) * WAVE;
+    if (m->parked_ok) return Bp < TILE_MAX ? Bp : TILE_MAX;
     double per_cfg = 1.0;
-    for (int c = 0; c < 4; ++c) if (m->cls_count[c] > 0) { const double v = (double)NSUB * m->cls_count[c] / m->d.cls_groups[c]; if (v > per_cfg) per_cfg = v; }
+    for (int c = 0; c < 4; ++c) if (pc.n[c] > 0) { const double v = (double)NSUB * pc.n[c] / m->d.cls_groups[c]; if (v > per_cfg) per_cfg = v; }
     const int64_t P = (int64_t)per_cfg + 1;
-    // scenes with many pairs get up to 8 GiB (of 288 GB) so that a tile still fills the chip
-    const size_t ws_max = m->n_pairs > 512 ? (size_t(8) << 30) : WS_MAX_BYTES;
+    const size_t ws_max = size_t(8) << 30;
     int64_t t = (int64_t)((ws_max - ws_header(m)) / (8 * (size_t)P)) - (int64_t)NSUB * WAVE;
     t = (t / WAVE) * WAVE;
-    // never less than two blocks per sub-queue: scenes with thousands of pairs get a workspace above WS_MAX_BYTES instead
-    // of tiles too small to fill the chip (288 GB of HBM: 3 GB for 11 000 pairs)
     if (t < 2 * (int64_t)NSUB * WAVE) t = 2 * (int64_t)NSUB * WAVE;
-    return B < t ? ((B + WAVE - 1) / WAVE) * WAVE : t;
+    if (t > TILE_MAX) t = TILE_MAX;
+    return Bp < t ? Bp : t;
+}
+static inline unsigned long long tile_queue_cap(const nbk_model* m, const PairCounts& pc, unsigned long long nblk) {
+    const unsigned long long worst = sub_queue_cap(m, pc, nblk);
+    if (!m->parked_ok) return worst;
+    size_t bytes = g_opt.queue_budget > 0 ? (size_t)g_opt.queue_budget : WS_MAX_BYTES;
+    if (bytes > 2 * ws_header(m)) bytes -= ws_header(m);           // the whole workspace, tables included, stays within the budget
+    unsigned long long budget = (unsigned long long)(bytes / (8 * (size_t)NSUB));
+    if (budget < (unsigned long long)WAVE) budget = WAVE;
+    return worst < budget ? worst : budget;
 }
 
 static inline size_t broad_reg_lds(const nbk_model* m, int S) {
@@ -3517,13 +3639,13 @@ static int32_t grow_scratch(hipStream_t st, void*& buf, size_t& have, size_t nee
 // queue fits the workspace.  `iw`: the workspace is this stream's own set and keeps state between calls (tables, counter epoch);
 // nullptr: caller-owned workspace, or a call being captured into a graph -- self-contained: every call prepares its tables
 // and clears its counters itself.
-static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                                       uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw) {
     unsigned long long* count_set0 = static_cast<unsigned long long*>(workspace);
     unsigned long long* count = count_set0;
     unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_header(m));
     const bool internal = iw != nullptr;
-    const int64_t tile = tile_configs(m, B);
+    const int64_t tile = tile_configs(m, pc, B);
     // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
     // distance predicate only, else the build with both
     bool any_zero = false, any_nonzero = false, any_negative = false;
@@ -3539,9 +3661,12 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const doub
         const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
         const unsigned nblk = blocks_for(nb);
         // a sub-queue takes one kind class of the blocks of one group (every 64th block): worst case all pairs of that class
-        const unsigned long long cap_sub = sub_queue_cap(m, nblk);
+        const unsigned long long cap_sub = tile_queue_cap(m, pc, nblk);
         EdgeSrc es_tile = es;
         if (es.map != nullptr) { es_tile.map = es.map + b0; es_tile.b0 = b0; }
+        es_tile.ovf = m->parked_ok ? reinterpret_cast<unsigned char*>(workspace) + ws_tables(m) : nullptr;
+        unsigned long long* flag_words = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_tables(m));
+        const int n_flag_words = m->parked_ok ? (int)((nblk + 7) / 8) : 0;
         // tiles start on a multiple of 64 configurations, so mask words never straddle tiles
         const double* qt = q ? q + b0 * m->n_q : nullptr;
         uint64_t* mb = mask_bits ? mask_bits + b0 / 64 : nullptr;
@@ -3558,14 +3683,14 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const doub
                 count_next = count_set0 + (size_t)((iw->epoch + 1u) & 1u) * NSUB * CNT_STRIDE;
             } else {
                 count = count_set0;
-                hipLaunchKernelGGL(k_prepare_f32, dim3(1), dim3(NSUB), 0, st, m->d, threshold, count_set0, internal ? 2 : 1, ftab);   // clears the counters too
+                hipLaunchKernelGGL(k_prepare_f32, dim3(1), dim3(NSUB), 0, st, m->d, threshold, count_set0, internal ? 2 : 1, ftab, flag_words, n_flag_words);   // clears the counters too
                 if (internal) { iw->ready = true; iw->thr = threshold; iw->epoch = 0; count_next = count_set0 + (size_t)NSUB * CNT_STRIDE; }
             }
             if (internal) iw->epoch += 1u;
         } else {
             count = count_set0;
             if (internal) iw->ready = false;
-            hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count);
+            hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count, flag_words, n_flag_words);
         }
         if (use_reg && f32 && S <= 8)
             hipLaunchKernelGGL(k_broad_f32<8>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
@@ -3595,30 +3720,35 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, EdgeSrc es, const doub
         else
             hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         NBK_HIP(hipGetLastError());
+        // blocks whose items overflowed their sub-queue (possible only when the budget, not the worst case, sized the queue)
+        if (m->parked_ok && cap_sub < sub_queue_cap(m, pc, nblk)) {
+            hipLaunchKernelGGL(k_validity_redo, dim3(nblk), dim3(WAVE), collide_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my);
+            NBK_HIP(hipGetLastError());
+        }
     }
     return NBK_OK;
 }
 
-static int32_t launch_two_kernel(const nbk_model* m, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
+static int32_t launch_two_kernel(const nbk_model* m, const PairCounts& pc, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                                  uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw = nullptr) {
-    const int32_t rc = launch_two_kernel_impl(m, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, iw);
+    const int32_t rc = launch_two_kernel_impl(m, pc, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, iw);
     if (rc != NBK_OK && iw != nullptr) iw->ready = false;      // whatever state the queues are in: start over
     return rc;
 }
 
-static int64_t two_kernel_workspace_bytes(const nbk_model* m, int64_t B) {
-    const int64_t nblk = (tile_configs(m, B) + WAVE - 1) / WAVE;
-    return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * (int64_t)sub_queue_cap(m, (unsigned long long)nblk);
+static int64_t two_kernel_workspace_bytes(const nbk_model* m, const PairCounts& pc, int64_t B) {
+    const int64_t nblk = (tile_configs(m, pc, B) + WAVE - 1) / WAVE;
+    return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * (int64_t)tile_queue_cap(m, pc, (unsigned long long)nblk);
 }
 
 int64_t nbk_validity_workspace_bytes(const nbk_model* m, int64_t B) {
     if (m == nullptr || B < 0) return NBK_ERR_INVALID;
     if ((B < g_opt.two_kernel_min_b && m->parked_ok) || m->n_pairs == 0 || B == 0) return 0;
     // NSUB sub-queues, each sized for the blocks that map to it (rounded up)
-    return two_kernel_workspace_bytes(m, B);
+    return two_kernel_workspace_bytes(m, all_pairs(m), B);        // the caller's workspace serves every threshold
 }
 
-static const EdgeSrc NO_EDGES = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+static const EdgeSrc NO_EDGES = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
 
 int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                               uint8_t* mask_bytes, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -3634,16 +3764,19 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
         NBK_HIP(hipGetLastError());
         return NBK_OK;
     }
-    return launch_two_kernel(m, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, workspace, st);
+    return launch_two_kernel(m, all_pairs(m), NO_EDGES, q, B, threshold, mask_bits, mask_bytes, workspace, st);
 }
 
 int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                            uint8_t* mask_bytes, void* stream) {
     if (m == nullptr) return NBK_ERR_INVALID;
-    const int64_t need = nbk_validity_workspace_bytes(m, B);
-    if (need <= 0) return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, nullptr, 0, stream);
+    if (nbk_validity_workspace_bytes(m, B) <= 0) return nbk_validity_batch_ws(m, q, B, threshold, mask_bits, mask_bytes, nullptr, 0, stream);
     if (B < 0 || q == nullptr || (mask_bits == nullptr && mask_bytes == nullptr)) return NBK_ERR_INVALID;
     NBK_DEVICE(m);
+    // the library's own scratch is sized for the pairs that are within reach at THIS threshold (obstacle-rich scenes: most world
+    // shapes are out of the arm's reach for good)
+    const PairCounts pc = reachable_pairs(m, threshold);
+    const int64_t need = two_kernel_workspace_bytes(m, pc, B);
     hipStream_t st = (hipStream_t)stream;
     StreamWs* w = stream_ws(const_cast<nbk_model*>(m), st);
     if (w == nullptr) { snprintf(g_err, sizeof(g_err), "more than 64 streams use this descriptor's internal workspaces: pass your own (nbk_validity_batch_ws)"); return NBK_ERR_ALLOC; }
@@ -3658,11 +3791,12 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
         w->ready = false;
         const int32_t rc = grow_scratch(st, w->ws, w->ws_bytes, (size_t)need, "hipMalloc(workspace)");
         if (rc != NBK_OK) return rc;
+        NBK_HIP(hipMemsetAsync(static_cast<char*>(w->ws) + ws_tables(m), 0, WS_FLAGS, st));      // no overflow marks yet
     }
     // a captured call must be self-contained (it is replayed out of order with the host-side state): prepare + clear inside
     // the graph, and the next direct call starts from scratch as well
     if (capturing) w->ready = false;
-    return launch_two_kernel(m, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w);
+    return launch_two_kernel(m, pc, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w);
 }
 
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
@@ -3759,13 +3893,14 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
         // keep a synchronous sizing step (one read-back) and cannot be captured
         if (capturing) { snprintf(g_err, sizeof(g_err), "graph capture of edge batches needs a robot that fits the LDS-parked layout"); return NBK_ERR_UNSUPPORTED; }
     }
+    const PairCounts pc = reachable_pairs(m, threshold);
     double* plan = nullptr;
     unsigned long long *cnt = nullptr, *offs = nullptr, *map = nullptr;
     uint8_t* ovf = nullptr;
     uint64_t* words = nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const bool fits = w->ecap_edges >= E && w->ecap_samples >= cap && w->stats != nullptr &&
-                          w->ws_bytes >= (size_t)two_kernel_workspace_bytes(m, (int64_t)w->ecap_samples);
+                          w->ws_bytes >= (size_t)two_kernel_workspace_bytes(m, pc, (int64_t)w->ecap_samples);
         if (!fits) {
             if (capturing) {
                 snprintf(g_err, sizeof(g_err), "graph capture: this stream's edge scratch is not allocated for %lld edges yet -- run the "
@@ -3785,11 +3920,12 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
             int32_t rc = grow_scratch(st, w->ews, w->ews_bytes, head_n + map_n + words_n, "hipMalloc(edge scratch)");
             if (rc != NBK_OK) return rc;
             w->ecap_edges = ne; w->ecap_samples = nc;
-            const size_t need = (size_t)two_kernel_workspace_bytes(m, (int64_t)nc);
+            const size_t need = (size_t)two_kernel_workspace_bytes(m, pc, (int64_t)nc);
             if (w->ws_bytes < need) {
                 w->ready = false;
                 rc = grow_scratch(st, w->ws, w->ws_bytes, need, "hipMalloc(workspace)");
                 if (rc != NBK_OK) return rc;
+                NBK_HIP(hipMemsetAsync(static_cast<char*>(w->ws) + ws_tables(m), 0, WS_FLAGS, st));
             }
         }
         cap = w->ecap_samples;                                 // use all of what is there
@@ -3817,9 +3953,9 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
     }
     hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, map, cap, ovf);
     NBK_HIP(hipGetLastError());
-    EdgeSrc es{starts, goals, plan, map, offs + E, 0};
+    EdgeSrc es{starts, goals, plan, map, offs + E, 0, nullptr};
     if (capturing) w->ready = false;
-    const int32_t rc = launch_two_kernel(m, es, nullptr, (int64_t)cap, threshold, words, nullptr, w->ws, st, capturing ? nullptr : w);
+    const int32_t rc = launch_two_kernel(m, pc, es, nullptr, (int64_t)cap, threshold, words, nullptr, w->ws, st, capturing ? nullptr : w);
     if (rc != NBK_OK) return rc;
     hipLaunchKernelGGL(k_edge_reduce, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, words, ovf, valid, w->stats_dev);
     NBK_HIP(hipGetLastError());

@@ -916,6 +916,20 @@ def test_scene_with_hundreds_of_obstacles(fresh_world, torch_cuda):
         with fused_path():
             assert np.array_equal(arm.in_collision(q[:2000], thr), ref[:2000])          # fused kernel
     assert 0.05 < orc.validity(q, 0.0, nthreads=8).mean() < 0.95
+    # a threshold at which many more of the 400 shapes come within reach (the queues are sized per threshold), and a batch
+    # large enough for several queue tiles: the library's own scratch stays within 1 GiB (+ the float32 tables)
+    ref = orc.validity(q, 0.6, nthreads=8)
+    assert np.array_equal(arm.in_collision(q, 0.6), ref) and ref.mean() > 0.5
+    torch = torch_cuda
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    qb = torch.from_numpy(sample_q(chain, 400000, seed=34)).cuda()
+    got = arm.in_collision(qb, 0.0)
+    torch.cuda.synchronize()
+    used = free0 - torch.cuda.mem_get_info()[0]
+    assert used < (1 << 30) + (200 << 20), used
+    sl = np.arange(0, 400000, 37)
+    assert np.array_equal(got.cpu().numpy()[sl], orc.validity(qb.cpu().numpy()[sl], 0.0, nthreads=8))
     dmin, idx = arm.closest_distance(q[:300])
     dref, iref = orc.closest(q[:300])
     assert_bitwise(dmin, dref, "closest among 4444 pairs")
@@ -1281,3 +1295,29 @@ def test_scalar_host_paths(fresh_world, torch_cuda):
     ok, end, ns = dev.edge_validity_scalar(q[3], q[150], 0.02, 1.0, mode="steer")
     o1, e1, n1 = orc.edge_validity(q[3:4], q[150:151], 0.02, 1.0, mode="steer")
     assert (ok, ns) == (bool(o1[0]), int(n1[0])) and np.array_equal(end, e1[0])
+
+
+def test_queue_overflow_is_redecided_without_a_queue(fresh_world, torch_cuda):
+    """The item queues are sized for a budget (1 GiB), not for the worst case; a block whose items do not fit marks itself and
+    k_validity_redo decides it the queue-less way.  With the budget shrunk to a few KB nearly every block overflows: same
+    masks, for plain batches (both workspaces, bit and byte masks) and for edge batches."""
+    torch = torch_cuda
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    q = sample_q(chain, 50000, seed=81)
+    refs = {thr: orc.validity(q, thr, nthreads=8) for thr in (0.0, 0.02)}
+    e_ref = orc.edge_validity(q[:1500], q[1500:3000], 0.03, 2.0, nthreads=8)
+    for budget in (1 << 12, 1 << 17, 1 << 21):
+        with debug_option("queue_budget", budget):
+            for thr, ref in refs.items():
+                assert np.array_equal(dev.validity(q, thr), ref), (budget, thr)
+                words = dev.validity(q, thr, packed=True)
+                from numbotics_amd.parallel import unpack_mask
+                assert np.array_equal(unpack_mask(words, 50000), ref), (budget, thr, "packed")
+            need = dev.validity_workspace_bytes(50000)
+            ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+            assert np.array_equal(dev.validity(q, 0.0, workspace=ws), refs[0.0]), (budget, "caller workspace")
+            ok, end, ns = dev.edge_validity(q[:1500], q[1500:3000], 0.03, 2.0)
+            assert np.array_equal(ok, e_ref[0]) and np.array_equal(ns, e_ref[2]), (budget, "edges")
+    assert np.array_equal(dev.validity(q, 0.0), refs[0.0])                 # and back at the default budget

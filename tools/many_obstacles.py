@@ -20,4 +20,5 @@ for W in (10, 100, 400, 1000):
     for _ in range(5): m = dev.validity(q, 0.0, packed=False)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)/5
+    free0 = torch.cuda.mem_get_info()[0]
     print('W %4d pairs %5d: %.3f ms per 1e6 -> %.3e configs/s, colliding %.3f' % (W, sm.n_pairs, ms, 1e9/ms, m.float().mean().item()), flush=True)
