@@ -31,10 +31,14 @@ def _is_tensor(x):
 
 class Arm(Robot):
 
-    def __init__(self, chain, weld_filter: bool = False, compound: bool = True):
+    def __init__(self, chain, weld_filter: bool = False, compound: bool = True, bullet_margins: bool = False):
+        """``bullet_margins`` (additive, default False = sharp shapes): give every box / cylinder / mesh hull that has no explicit
+        ``collision_margin`` the margin Bullet itself applies (robots/model.py ``bullet_margin``) -- the mode to expect closest to
+        the reference's PyBullet distances; can be switched later through the ``bullet_margins`` property."""
         super().__init__(chain)
         self._weld_filter = weld_filter
         self._compound = compound
+        self._bullet_margins = bool(bullet_margins)
         self._kin = compile_kinematics(chain)
         # per-frame flattened sequences in the reference's own format (arm.py:61), kept for inspection
         self._link_joint_sequence = {}
@@ -238,14 +242,23 @@ class Arm(Robot):
             return (order[a._name], kb)
         return sorted(pairs, key=key)
 
+    @property
+    def bullet_margins(self) -> bool:
+        return self._bullet_margins
+
+    @bullet_margins.setter
+    def bullet_margins(self, on: bool):
+        self._bullet_margins = bool(on)
+        self._scene_cache = None
+
     def scene_model(self, pairs=None):
         """The flat SceneModel (robots/model.py) of the current world and pair set."""
         if pairs is not None:
-            return compile_scene(self._chain, self._refreshed_kin(), self._sorted_pairs(pairs), self._compound)
-        key = (self._chain.world._revision, self._pairs_version)
+            return compile_scene(self._chain, self._refreshed_kin(), self._sorted_pairs(pairs), self._compound, self._bullet_margins)
+        key = (self._chain.world._revision, self._pairs_version, self._bullet_margins)
         if self._scene_cache is None or self._scene_cache[0] != key:
             sm = compile_scene(self._chain, self._refreshed_kin(), self._sorted_pairs(self.collision_pairs()),
-                               self._compound)
+                               self._compound, self._bullet_margins)
             self._scene_cache = (key, sm, None)
         return self._scene_cache[1]
 

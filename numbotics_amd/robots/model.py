@@ -164,7 +164,32 @@ class HullTable:
                 np.array(self.face_begin, dtype=np.int32), np.ascontiguousarray(P, dtype=np.float64))
 
 
-def _shape_records(cs, owner_pose_local: np.ndarray, hulls: HullTable):
+BULLET_MARGIN = 0.04          # btCollisionShape's CONVEX_DISTANCE_MARGIN
+BULLET_HULL_MARGIN = 0.001    # what pybullet's createCollisionShape gives the convex hulls of a GEOM_MESH
+
+
+def bullet_margin(shape, info) -> float:
+    """The collision margin Bullet itself would give this shape (``bullet_margins=True`` scenes; third-party behaviour restated
+    from Bullet's public sources, NOT pinned: pybullet is absent).  btBoxShape / btCylinderShape shrink their implicit
+    dimensions by the margin and add it back as a rounding -- exactly this build's ``core (+) ball(margin)`` -- with the margin
+    limited to a tenth of the smallest half extent (setSafeMargin); spheres and capsules are exact; a hull is inflated."""
+    if shape in (Shape.CUBE, Shape.CUBOID):
+        return float(min(BULLET_MARGIN, 0.1 * np.min(np.asarray(info['half_extents'], dtype=np.float64))))
+    if shape == Shape.CYLINDER:
+        return float(min(BULLET_MARGIN, 0.1 * min(float(info['radius']), float(info['height']) / 2.0)))
+    if shape == Shape.MESH:
+        return BULLET_HULL_MARGIN
+    return 0.0
+
+
+def _margin(cs, bullet_margins: bool) -> float:
+    info = cs._shape_info
+    if 'collision_margin' in info:
+        return float(info['collision_margin'])
+    return bullet_margin(cs.shape, info) if bullet_margins else 0.0
+
+
+def _shape_records(cs, owner_pose_local: np.ndarray, hulls: HullTable, bullet_margins: bool = False):
     """[(type, 3x4 pose in the owner frame, params[4])] for one CollisionShape: one record, except for a MESH, which
     yields one convex hull per object of its file (numbotics/utils/shape.py:81-94 -> Bullet GEOM_MESH)."""
     if cs.shape == Shape.MESH:
@@ -178,18 +203,18 @@ def _shape_records(cs, owner_pose_local: np.ndarray, hulls: HullTable):
             Tc[:3, 3] = T[:3, :3] @ part.center + T[:3, 3]          # the hull's local origin = the mean of its vertices
             p = np.zeros(4)
             p[0] = float(hulls.add(part))
-            p[3] = float(info.get('collision_margin', 0.0))
+            p[3] = _margin(cs, bullet_margins)
             out.append((SH_HULL, Tc, p))
         return out
-    return [_shape_record(cs, owner_pose_local)]
+    return [_shape_record(cs, owner_pose_local, bullet_margins)]
 
 
-def _shape_record(cs, owner_pose_local: np.ndarray):
+def _shape_record(cs, owner_pose_local: np.ndarray, bullet_margins: bool = False):
     """(type, 3x4 pose in the owner frame, params[4]) for one primitive CollisionShape."""
     info = cs._shape_info
     T = owner_pose_local @ cs.offset
     p = np.zeros(4)
-    p[3] = float(info.get('collision_margin', 0.0))
+    p[3] = _margin(cs, bullet_margins)
     if cs.shape in (Shape.CUBE, Shape.CUBOID):
         p[0:3] = np.asarray(info['half_extents'], dtype=np.float64)
         return SH_BOX, T, p
@@ -258,8 +283,10 @@ class SceneModel:
         return subj, self.objects[self.wshape_obj[b - self.n_rshapes]]
 
 
-def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> SceneModel:
-    """``pairs``: iterable of (Link, Link | PhysicsObject) as produced by ``Arm.collision_pairs()``."""
+def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True, bullet_margins: bool = False) -> SceneModel:
+    """``pairs``: iterable of (Link, Link | PhysicsObject) as produced by ``Arm.collision_pairs()``.
+    ``bullet_margins``: shapes without an explicit ``collision_margin`` get the margin Bullet would give them
+    (``bullet_margin`` above) instead of 0 -- the setting closest to what the reference's ``getClosestPoints`` measures."""
     from numbotics_amd.physics import PhysicsObject, Link
     links = chain._links
     link_index = {l._name: i for i, l in enumerate(links)}
@@ -274,7 +301,7 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
         for cs in shapes:
             if cs.shape == Shape.EMPTY:
                 continue
-            for t, T, p in _shape_records(cs, fr.local, hulls):
+            for t, T, p in _shape_records(cs, fr.local, hulls, bullet_margins):
                 if t == SH_PLANE:
                     raise ValueError("a PLANE cannot be a robot link shape")
                 ids.append(len(r_type))
@@ -308,7 +335,7 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True) -> S
             if key not in shapes_of_obj:
                 ids = []
                 if b._collision_shape.shape != Shape.EMPTY:
-                    for t, T, p in _shape_records(b._collision_shape, b.pose, hulls):
+                    for t, T, p in _shape_records(b._collision_shape, b.pose, hulls, bullet_margins):
                         ids.append(len(w_type))
                         w_type.append(t)
                         w_pose.append(_T34(T))

@@ -40,14 +40,14 @@ def apply_rrt_script_removals(arm):
         logger.VERBOSE = verbose
 
 
-def build_scene(name: str = "c2", urdf: str = None):
+def build_scene(name: str = "c2", urdf: str = None, bullet_margins: bool = False):
     """-> (arm, chain, obstacles).  Keep the returned obstacles alive: the world holds weak references."""
     from numbotics_amd.physics import GraphChain, Cube, Mesh
     from numbotics_amd.robots import Arm
     if urdf is None:
         urdf = KINOVA_MESH_URDF if name in ("c2m", "c5m") else KINOVA_URDF
     chain = GraphChain.from_urdf(urdf)
-    arm = Arm(chain)
+    arm = Arm(chain, bullet_margins=bullet_margins)
     obstacles = []
     if name == "c1":
         pass

@@ -1321,3 +1321,37 @@ def test_queue_overflow_is_redecided_without_a_queue(fresh_world, torch_cuda):
             ok, end, ns = dev.edge_validity(q[:1500], q[1500:3000], 0.03, 2.0)
             assert np.array_equal(ok, e_ref[0]) and np.array_equal(ns, e_ref[2]), (budget, "edges")
     assert np.array_equal(dev.validity(q, 0.0), refs[0.0])                 # and back at the default budget
+
+
+@pytest.mark.parametrize("scene", ["c2", "c3", "c5m"])
+def test_bullet_margin_mode(fresh_world, scene, torch_cuda):
+    """``Arm(chain, bullet_margins=True)``: every box / cylinder / mesh hull without an explicit margin gets the one Bullet applies
+    (min(0.04, a tenth of the smallest half extent); hulls 0.001) -- the scene closest to what the reference's getClosestPoints
+    measures.  Same bar as the sharp scenes: masks at four thresholds (all three validity paths), distances, witnesses and
+    gradient rows bit for bit against the oracle.  (Parity with Bullet itself stays unpinned.)"""
+    arm, chain, obs = build_scene(scene, bullet_margins=True)
+    sm = arm.scene_model()
+    assert (sm.rshape_param[:, 3] > 0).sum() >= 9 and (sm.wshape_param[:, 3] > 0).all()
+    sharp = build_scene  # noqa: F841
+    orc = Oracle(sm)
+    q = sample_q(chain, 20000, seed=2)
+    for thr in (0.0, 1e-6, 0.02, -0.005):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref), (scene, thr)
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), (scene, thr, "fused")
+        with debug_option("f64_broad", 1):
+            assert np.array_equal(arm.in_collision(q, thr), ref), (scene, thr, "float64 broadphase")
+    d, w, rows = arm.proximity_jacobians(q[:1500])
+    dr, wr, rr = orc.proximity_jacobian(q[:1500])
+    assert_bitwise(d, dr, "bullet-margin distances")
+    assert_bitwise(w, wr, "bullet-margin witnesses")
+    assert_bitwise(rows, rr, "bullet-margin rows")
+    dmin, idx = arm.closest_distance(q[:3000])
+    dref, iref = orc.closest(q[:3000])
+    assert_bitwise(dmin, dref, "bullet-margin closest")
+    assert np.array_equal(idx, iref)
+    # switching the mode on an existing arm recompiles the scene
+    arm.bullet_margins = False
+    assert (arm.scene_model().rshape_param[:, 3] == 0).all()
+    assert np.array_equal(arm.in_collision(q[:5000]), Oracle(arm.scene_model()).validity(q[:5000]))

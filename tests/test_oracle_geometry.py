@@ -100,3 +100,35 @@ def test_degenerate_inputs_do_not_blow_up():
     T = np.eye(4); T[:3, 3] = [0.5, 0, 0.2]
     d = shape_distance(CAPSULE, I, [0.1, 0.4, 0, 0], CAPSULE, T, [0.1, 0.4, 0, 0])[0]
     assert d == pytest.approx(0.3, abs=1e-15)
+
+
+def test_bullet_margins_match_truth_on_rounded_shapes():
+    """``bullet_margins=True`` scenes: boxes / cylinders carry margin = min(0.04, a tenth of the smallest half extent) and are the
+    Minkowski sum core (+) ball(margin) -- what Bullet's btBoxShape / btCylinderShape are.  Distances of such rounded shapes against
+    the SLSQP truth, and the margin rule itself."""
+    from numbotics_amd.robots.model import bullet_margin
+    from numbotics_amd.utils import Shape
+    assert bullet_margin(Shape.CUBE, {'half_extents': np.array([0.4, 0.4, 0.4])}) == 0.04
+    assert np.isclose(bullet_margin(Shape.CUBOID, {'half_extents': np.array([0.03, 0.06, 0.045])}), 0.003)
+    assert np.isclose(bullet_margin(Shape.CYLINDER, {'radius': 0.05, 'height': 0.12}), 0.005)
+    assert bullet_margin(Shape.SPHERE, {'radius': 0.1}) == 0.0 and bullet_margin(Shape.CAPSULE, {'radius': 0.1, 'height': 1.0}) == 0.0
+    assert bullet_margin(Shape.MESH, {}) == 0.001
+    rng = np.random.default_rng(29)
+    worst, n = 0.0, 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(250):
+            ta, tb = int(rng.choice([BOX, CYLINDER])), int(rng.integers(0, 4))
+            Ta, Tb = random_pose(rng, 0.35), random_pose(rng, 0.35)
+            pa, pb = random_param(rng, ta), random_param(rng, tb)
+            pa[3] = min(0.04, 0.1 * (pa[:3].min() if ta == BOX else min(pa[0], pa[1])))
+            if tb in (BOX, CYLINDER):
+                pb[3] = min(0.04, 0.1 * (pb[:3].min() if tb == BOX else min(pb[0], pb[1])))
+            d = shape_distance(ta, Ta, pa, tb, Tb, pb)[0]
+            dt, dc = truth_distance(ta, Ta, pa, tb, Tb, pb)
+            if dc > 1e-6:
+                n += 1
+                worst = max(worst, abs(d - dt))
+            for thr in (0.0, 0.02, d * (1 + 1e-6), d * (1 - 1e-6)):
+                assert shape_collides(ta, Ta, pa, tb, Tb, pb, thr) == (d < thr)
+    assert n > 100 and worst < 1e-8, (n, worst)
