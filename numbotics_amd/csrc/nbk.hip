@@ -187,6 +187,13 @@ NBK_DEV double edge_t(const EdgeSrc& es, unsigned long long mp, unsigned& e_out)
     return ((double)i < pl[2]) ? (double)i * pl[0] : pl[1];
 }
 
+// 16-byte store of an output row.  (Non-temporal stores -- __builtin_nontemporal_store -- were tried for the pose / Jacobian streams:
+// 12-15x SLOWER on gfx950, k_fk_frames 0.39 -> 6.2 ms per 1e6; plain stores through L2 it is.)
+NBK_DEV void store_stream2(double* dst, double x, double y) {
+    double2 v; v.x = x; v.y = y;
+    *reinterpret_cast<double2*>(dst) = v;
+}
+
 // ---- q staging: rows [B][n_q] -> LDS [n_q][64] ---------------------------------------------------
 // The block's slab of q is contiguous (64*n_q doubles); it is read with 16-byte loads where the slab is
 // full, then each lane picks its own row out of LDS.
@@ -345,12 +352,7 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
     for (int kk = 0; kk < 8; ++kk) {
         const int g = lane + WAVE * kk;   // double2 index inside the block's 1024-double slab
         const int r = g >> 3, c2 = (g & 7) * 2;
-        if (r < rows) {
-            double2 v;
-            v.x = lds[r * 17 + c2];
-            v.y = lds[r * 17 + c2 + 1];
-            dst[g] = v;
-        }
+        if (r < rows) store_stream2(reinterpret_cast<double*>(dst + g), lds[r * 17 + c2], lds[r * 17 + c2 + 1]);
     }
 }
 
@@ -581,10 +583,7 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
         int o = r * stride + c;
         if (wide) {
             for (; g < total; g += 2 * WAVE) {
-                double2 v;
-                v.x = lds_o[o];
-                v.y = lds_o[o + 1];
-                *reinterpret_cast<double2*>(d + g) = v;
+                store_stream2(d + g, lds_o[o], lds_o[o + 1]);
                 c += step_c; o += step_r * stride + step_c;
                 if (c >= ncol) { c -= ncol; o += stride - ncol; }
             }
@@ -659,12 +658,7 @@ __global__ __launch_bounds__(64) void k_fk_frames(DevModel m, const double* __re
             for (int kk = 0; kk < 8; ++kk) {
                 const int g = lane + WAVE * kk;                // double2 index inside this frame's 64 x 16 slab
                 const int r = g >> 3, c2 = (g & 7) * 2;
-                if (r < rows) {
-                    double2 v;
-                    v.x = lds_t[r * 17 + c2];
-                    v.y = lds_t[r * 17 + c2 + 1];
-                    *reinterpret_cast<double2*>(T_out + ((size_t)(base + r) * n_frames + fo) * 16 + c2) = v;
-                }
+                if (r < rows) store_stream2(T_out + ((size_t)(base + r) * n_frames + fo) * 16 + c2, lds_t[r * 17 + c2], lds_t[r * 17 + c2 + 1]);
             }
         }
     }
@@ -1263,9 +1257,11 @@ __global__ void k_zero_counters(unsigned long long* __restrict__ q_count, unsign
 //   wcin [W*16] float  world boxes: (thr + inA + mBox - f_e2max)^2 against the centre's squared distance to the (core) box
 //   rptri[128]  int    sorted pair index of robot-robot slot (a,b) at its triangular index b(b-1)/2 + a
 //   wlist[W], n_reach  int   the world shapes some robot shape can reach at this threshold, ascending; the world loop visits only those
-NBK_DEV size_t ftab_entries(int W) { return 3 * 256 + 128 + 5 * (size_t)W * 16 + 32 + (size_t)W + 16; }
+//   rkey2[16*16], wkey2[W*16] float  the candidate thresholds with the STATIC slack folded in and squared ((rs + f_e2max)^2; planes: the
+//               height rs + rhoA + f_e2max): scalars for the waves whose lanes all stay within the static slack
+NBK_DEV size_t ftab_entries(int W) { return 4 * 256 + 128 + 6 * (size_t)W * 16 + 32 + (size_t)W + 16; }
 struct FTab {
-    const float *rkey, *rcert, *wkey, *wtc, *wcert, *wcin, *rho;
+    const float *rkey, *rcert, *wkey, *wtc, *wcert, *wcin, *rho, *rkey2, *wkey2;
     const int *rp, *rptri, *wp, *wlist, *n_reach;
 };
 NBK_DEV FTab ftab_view(const float* tab, int W) {
@@ -1276,6 +1272,7 @@ NBK_DEV FTab ftab_view(const float* tab, int W) {
     t.wkey = tab + 896; t.wtc = t.wkey + w16; t.wp = reinterpret_cast<const int*>(t.wtc + w16);
     t.wcert = t.wtc + 2 * w16; t.wcin = t.wcert + w16; t.rho = t.wcin + w16;
     t.n_reach = reinterpret_cast<const int*>(t.rho + 32); t.wlist = t.n_reach + 16;
+    t.rkey2 = reinterpret_cast<const float*>(t.wlist + W); t.wkey2 = t.rkey2 + 256;
     return t;
 }
 
@@ -1296,9 +1293,12 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
         const float v = (float)c * dn - m.f_e2max * up;
         return v > 0.0f ? (v * v) * (dn * dn) : -1.0f;
     };
-    rkey[t] = -1.0f; rp[t] = -1; rcert[t] = -1.0f;
+    float* rkey2 = const_cast<float*>(v.rkey2); float* wkey2 = const_cast<float*>(v.wkey2);
+    // squared candidate threshold with the static slack: ((rs rounded up) + f_e2max)^2 rounded up; -1 = not a pair
+    auto cand2 = [&](float rs_up) { const float r = (rs_up + m.f_e2max) * up; return (r * r) * (up * up); };
+    rkey[t] = -1.0f; rp[t] = -1; rcert[t] = -1.0f; rkey2[t] = -1.0f;
     if (t < 128) rptri[t] = -1;
-    for (int i = t; i < W * 16; i += 256) { wkey[i] = -1.0f; wtc[i] = 0.0f; wp[i] = -1; wcert[i] = -3.0e38f; wcin[i] = -1.0f; }
+    for (int i = t; i < W * 16; i += 256) { wkey[i] = -1.0f; wtc[i] = 0.0f; wp[i] = -1; wcert[i] = -3.0e38f; wcin[i] = -1.0f; wkey2[i] = -3.0e38f; }
     if (t < 16) rho[t] = t < m.n_rshapes ? (float)m.rs_core[6 * t + 5] * up : 0.0f;
     __syncthreads();
     const int P = (NBK_DBG(m) & 2) ? 0 : m.n_pairs;
@@ -1312,6 +1312,7 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
             const double rs = (tc + cst[2]) + cst[3];
             const int lo = a < b ? a : b, hi = a < b ? b : a;
             rkey[lo * 16 + hi] = rs > 0.0 ? (float)rs * up : -1.0f;
+            rkey2[lo * 16 + hi] = rs > 0.0 ? cand2((float)rs * up) : -1.0f;
             rp[lo * 16 + hi] = p;
             rptri[hi * (hi - 1) / 2 + lo] = p;
             rcert[lo * 16 + hi] = cert2((thr + m.rs_in[a]) + m.rs_in[b]);
@@ -1339,6 +1340,9 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
                 wcin[w * 16 + a] = cert2((thr + m.rs_in[a]) + cst[1]);
             }
             wkey[w * 16 + a] = key;
+            // planes: candidate iff hc - rhoA < key + slack  <=>  hc < key + rhoA + slack
+            wkey2[w * 16 + a] = cat == 0 ? ((key + rho[a]) + m.f_e2max * up) + __builtin_fabsf(key + rho[a]) * 2.4e-7f
+                                         : (key >= 0.0f ? cand2(key) : -1.0f);
             wp[w * 16 + a] = p;
         }
     }
@@ -1980,10 +1984,130 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     // f_e2max, so they are scalars; a lane whose own slack is larger (prismatic travel, huge joint values) never certifies.
     // A configuration known to collide queues nothing: the world shapes go first, then the robot rows -- a hit found in a row
     // stops that row and the later ones (the earlier rows' items stay: 0.097 instead of 0.088 items per configuration).
-    const bool cert_ok = e2 <= m.f_e2max;
-    bool certh = false;
     int qn = 0;
     const int n_reach = *ft.n_reach;
+    // ---- fast pair stage: every lane of the wave is within the static slack bound (always, for revolute robots with |q| sums below
+    // 64 rad), so every threshold is a scalar that k_prepare_f32 has squared already: a slot costs the squared centre distance and
+    // two compares.  The compare results stay lane masks in scalar registers -- no per-lane survivor bits -- and are queued slot by
+    // slot (a pair at a time) after the world shape's / the row's certified hits are known.
+    if (__builtin_amdgcn_ballot_w64(!(e2 <= m.f_e2max)) == 0ull) {
+        const float* tab_rkey2 = ft.rkey2;
+        const float* tab_wkey2 = ft.wkey2;
+#define NBK_ENQUEUE(cond_, pidx_)                                                                                               \
+        {                                                                                                                       \
+            const bool c_ = (cond_);                                                                                            \
+            const unsigned long long cm_ = __builtin_amdgcn_ballot_w64(c_);                                                     \
+            if (cm_ != 0ull) {                                                                                                  \
+                if (c_) {                                                                                                       \
+                    const int pos_ = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm_ >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm_, 0u)); \
+                    lds_queue[pos_] = ((unsigned)(pidx_) << 6) | (unsigned)lane;                                                \
+                }                                                                                                               \
+                qn += __builtin_popcountll(cm_);                                                                                \
+                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }   \
+            }                                                                                                                   \
+        }
+        for (int wi = 0; wi < n_reach; ++wi) {
+            const int w = ft.wlist[wi];
+            const float* wc = m.f_tab + m.f_wc + 18 * w;
+            const int wk = m.ws_kind[w];
+            bool c[S];
+            bool ch = false;
+#pragma unroll
+            for (int a = 0; a < S; ++a) c[a] = false;
+            if (wk == K_PLANE) {
+#pragma unroll
+                for (int a = 0; a < S; ++a) {
+                    if (a < m.n_rshapes && tab_wp[w * 16 + a] >= 0) {
+                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                        const float hc = __builtin_fmaf(dz, wc[11], __builtin_fmaf(dy, wc[10], dx * wc[9]));
+                        c[a] = hc < tab_wkey2[w * 16 + a];
+                        ch = ch || (hc < tab_wcert[w * 16 + a]);
+                    }
+                }
+            } else if (wk == K_BOX) {
+#pragma unroll
+                for (int a = 0; a < S; ++a) {
+                    if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
+                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                        const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        bool cand = dd < tab_wkey2[w * 16 + a];
+                        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {         // exact-box midphase, as in the general stage below
+                            const float rs = tab_wkey[w * 16 + a], tc = tab_wtc[w * 16 + a], rho = tab_rho[a];
+                            float ex2 = 0.0f, g = 3.4e38f;
+                            bool inside = true;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const float axj = __builtin_fabsf(__builtin_fmaf(dz, wc[5 + 3 * j], __builtin_fmaf(dy, wc[4 + 3 * j], dx * wc[3 + 3 * j])));
+                                const float exj = axj - wc[12 + j];
+                                if (exj > 0.0f) { inside = false; ex2 = __builtin_fmaf(exj, exj, ex2); }
+                                g = __builtin_fminf(g, wc[12 + j] - axj);
+                            }
+                            if (!inside) {
+                                const float rr = (tc + rho) + e2;
+                                if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                                if (cand && ex2 < tab_wcin[w * 16 + a]) ch = true;
+                            } else if (cand && g > -tc + e2 && rs > e2 && dd * up < (rs - e2) * (rs - e2)) {
+                                ch = true;
+                            }
+                        }
+                        c[a] = cand;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < S; ++a) {
+                    if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
+                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                        const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        c[a] = dd < tab_wkey2[w * 16 + a];
+                        ch = ch || (dd < tab_wcert[w * 16 + a]);
+                    }
+                }
+            }
+            hit = hit || ch;
+            const bool live = active && !hit && !(NBK_DBG(m) & 4);
+            bool anyc = false;
+#pragma unroll
+            for (int a = 0; a < S; ++a) anyc = anyc || c[a];
+            if (__builtin_amdgcn_ballot_w64(anyc && live) != 0ull) {          // one branch per world shape; most have no candidate
+#pragma unroll
+                for (int a = 0; a < S; ++a)
+                    if (a < m.n_rshapes) NBK_ENQUEUE(c[a] && live, tab_wp[w * 16 + a]);
+            }
+        }
+        if (m.bq_count[1] > 0) {
+#pragma unroll
+            for (int a = 0; a < S - 1; ++a) {
+                bool c[S];
+                bool ch = false;
+#pragma unroll
+                for (int b = a + 1; b < S; ++b) {
+                    const float dx = cx[a] - cx[b], dy = cy[a] - cy[b], dz = cz[a] - cz[b];
+                    const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                    c[b] = dd < tab_rkey2[a * 16 + b];
+                    ch = ch || (dd < tab_rcert[a * 16 + b]);
+                }
+                hit = hit || ch;
+                const bool live = active && !hit;
+                bool anyc = false;
+#pragma unroll
+                for (int b = a + 1; b < S; ++b) anyc = anyc || c[b];
+                if (__builtin_amdgcn_ballot_w64(anyc && live) != 0ull) {      // one branch per row
+#pragma unroll
+                    for (int b = a + 1; b < S; ++b) NBK_ENQUEUE(c[b] && live, ft.rp[a * 16 + b]);
+                }
+            }
+        }
+#undef NBK_ENQUEUE
+        if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf);
+        const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
+        if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
+        if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+        return;
+    }
+    // ---- general pair stage (some lane's slack exceeds the static bound: prismatic travel, huge joint values) ----------------------
+    const bool cert_ok = e2 <= m.f_e2max;
+    bool certh = false;
     for (int wi = 0; wi < n_reach; ++wi) {
         const int w = ft.wlist[wi];                 // only the world shapes within somebody's reach at this threshold
         const float* wc = m.f_tab + m.f_wc + 18 * w;
@@ -3539,7 +3663,7 @@ static const size_t WS_FLAGS = (size_t)(TILE_MAX / WAVE);       // one overflow 
 static const size_t WS_COUNTER_SET = NSUB * CNT_STRIDE * 8;    // NSUB counters, one cache line each
 static const size_t WS_COUNTERS = 2 * WS_COUNTER_SET;          // two sets (see StreamWs::epoch)
 static inline size_t ws_tables(const nbk_model* m) {           // counters | per-call float32 broadphase tables
-    return (WS_COUNTERS + 4 * (3 * 256 + 128 + 5 * (size_t)m->d.n_wshapes * 16 + 32 + (size_t)m->d.n_wshapes + 16) + 255) & ~size_t(255);
+    return (WS_COUNTERS + 4 * (4 * 256 + 128 + 6 * (size_t)m->d.n_wshapes * 16 + 32 + (size_t)m->d.n_wshapes + 16) + 255) & ~size_t(255);
 }
 static inline size_t ws_header(const nbk_model* m) { return ws_tables(m) + WS_FLAGS; }      // ... | overflow marks | items follow
 
