@@ -1050,10 +1050,14 @@ static int gjkb_step(gjkb_t *g, const core_t *A, const core_t *Bc) {
     if (dot3(g->d, g->d) == 0.0) return 2;      /* the origin lies on the simplex */
     return 0;
 }
+static __thread long long g_gjkb_hist[40];       /* iterations of the boolean walk, per verdict (diagnostic) */
 static int gjk_intersect(const core_t *A, const core_t *Bc) {
     gjkb_t g;
     gjkb_init(&g, A, Bc);
-    for (;;) { const int r = gjkb_step(&g, A, Bc); if (r) return r == 2; }
+    for (;;) { const int r = gjkb_step(&g, A, Bc); if (r) { g_gjkb_hist[g.it < 39 ? g.it : 39] += 1; return r == 2; } }
+}
+void orc_gjkb_hist(long long *out, int reset) {
+    for (int i = 0; i < 40; ++i) { out[i] = g_gjkb_hist[i]; if (reset) g_gjkb_hist[i] = 0; }
 }
 
 /* bounding radius of a core about its centre (broadphase) */

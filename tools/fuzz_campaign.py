@@ -1,6 +1,8 @@
 """Randomised parity campaign (not part of the test suite): many random mechanisms / obstacle sets, large batches,
 several thresholds, device masks (two-kernel path with the float32 broadphase) against the CPU oracle.
-    python tools/fuzz_campaign.py [first_seed] [n_seeds] [configs_per_seed]"""
+    python tools/fuzz_campaign.py [first_seed] [n_seeds] [configs_per_seed]
+Every third seed builds its robot and obstacles WITH MESHES (random polytope files, scaled / offset / auto-centred / compound),
+every fourth compiles the scene with bullet_margins=True; NBK_FUZZ_ALL=1 adds every other entry point."""
 import os, sys, tempfile, numpy as np
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -20,11 +22,12 @@ with tempfile.TemporaryDirectory() as d:
         _reset_worlds(); World()
         rng = np.random.default_rng(seed)
         n_links = int(rng.integers(3, 17))
-        chain = GraphChain.from_urdf(random_urdf(rng, n_links, os.path.join(d, "f.urdf")))
+        meshes = seed % 3 == 0
+        chain = GraphChain.from_urdf(random_urdf(rng, n_links, os.path.join(d, "f.urdf"), meshes=meshes))
         if chain.dof == 0:
             continue
-        arm = Arm(chain)
-        obs = random_obstacles(rng, int(rng.integers(1, 9)))
+        arm = Arm(chain, bullet_margins=(seed % 4 == 0))
+        obs = random_obstacles(rng, int(rng.integers(1, 9)), mesh_dir=d if meshes else None)
         sm = arm.scene_model()
         if sm.n_pairs == 0:
             continue
@@ -32,7 +35,7 @@ with tempfile.TemporaryDirectory() as d:
         lim = np.asarray(chain.joint_limits, dtype=np.float64)
         lim = np.where(np.isfinite(lim), lim, np.sign(lim) * np.pi)
         q = rng.uniform(lim[:, 0], lim[:, 1], (B, chain.dof))
-        line = f"seed {seed}: links {n_links} dof {chain.dof} shapes {sm.n_rshapes}+{sm.n_wshapes} pairs {sm.n_pairs}"
+        line = f"seed {seed}: links {n_links} dof {chain.dof} shapes {sm.n_rshapes}+{sm.n_wshapes} pairs {sm.n_pairs} hulls {sm.n_hulls}" + (" bullet-margins" if seed % 4 == 0 else "")
         for thr in (0.0, 0.01, -0.002, 1e-6):
             ref = orc.validity(q, thr, nthreads=16)
             got = np.asarray(arm.in_collision(q, thr))
