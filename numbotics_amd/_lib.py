@@ -61,6 +61,12 @@ def load():
         raise NbkError(
             f"{LIB_PATH} is missing: build it with `python -m numbotics_amd.csrc.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback for the device path.")
+    # PyTorch-ROCm ships its own HIP runtime: load it first so that libnbk.so binds to the runtime torch uses (loaded the other
+    # way round the process ends up with two runtimes and torch sees no device)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.nbk_status_string.restype = C.c_char_p
     lib.nbk_status_string.argtypes = [C.c_int32]
