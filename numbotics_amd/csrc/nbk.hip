@@ -65,7 +65,7 @@ struct DevModel {
     // base[12] | [S][3] shape centre offsets | [W][18] world cores; slack = f_eps * max(f_reach, largest |coordinate| of
     // the configuration) covers the float32 error of the sweep 50 times over
     const float* f_tab;
-    int f_trans, f_slide, f_base, f_tl, f_wc;
+    int f_trans, f_slide, f_base, f_tl, f_wc, f_wobb;      // f_wobb: [W][6] local bounding boxes of world hulls (centre, half extents)
     float f_eps, f_reach;
     float f_e2max;                // static bound of the per-lane slack 2e: lanes above it (prismatic travel, |q| sums beyond 64 rad) do not certify hits
     const double* rs_in;          // [S] radius of a ball around the shape's centre that lies inside the shape (margin included)
@@ -2053,6 +2053,30 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                         c[a] = cand;
                     }
                 }
+            } else if (wk == K_HULL) {
+                const float* ob = m.f_tab + m.f_wobb + 6 * w;            // the hull's local bounding box
+#pragma unroll
+                for (int a = 0; a < S; ++a) {
+                    if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
+                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                        const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+                        bool cand = dd < tab_wkey2[w * 16 + a];
+                        ch = ch || (dd < tab_wcert[w * 16 + a]);
+                        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {     // centre against the hull's box: only a cull
+                            const float tc = tab_wtc[w * 16 + a], rho = tab_rho[a];
+                            float ex2 = 0.0f;
+#pragma unroll
+                            for (int j = 0; j < 3; ++j) {
+                                const float xj = __builtin_fmaf(dz, wc[5 + 3 * j], __builtin_fmaf(dy, wc[4 + 3 * j], dx * wc[3 + 3 * j])) - ob[j];
+                                const float exj = __builtin_fabsf(xj) - ob[3 + j];
+                                if (exj > 0.0f) ex2 = __builtin_fmaf(exj, exj, ex2);
+                            }
+                            const float rr = (tc + rho) + e2;
+                            if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                        }
+                        c[a] = cand;
+                    }
+                }
             } else {
 #pragma unroll
                 for (int a = 0; a < S; ++a) {
@@ -2163,6 +2187,8 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 }
             }
         } else {
+            const bool is_hull = wk == K_HULL;
+            const float* ob = m.f_tab + m.f_wobb + 6 * w;                // hulls: local bounding box (a cull, as in the fast stage)
 #pragma unroll
             for (int a = 0; a < S; ++a) {
                 if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
@@ -2170,7 +2196,20 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                     const float r = rs + e2;
                     const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
                     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    bits |= (rs >= 0.0f && dd < r * r * up) ? (1ull << a) : 0ull;
+                    bool cand = rs >= 0.0f && dd < r * r * up;
+                    if (is_hull && __builtin_amdgcn_ballot_w64(cand) != 0ull) {
+                        const float tc = tab_wtc[w * 16 + a], rho = tab_rho[a];
+                        float ex2 = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float xj = __builtin_fmaf(dz, wc[5 + 3 * j], __builtin_fmaf(dy, wc[4 + 3 * j], dx * wc[3 + 3 * j])) - ob[j];
+                            const float exj = __builtin_fabsf(xj) - ob[3 + j];
+                            if (exj > 0.0f) ex2 = __builtin_fmaf(exj, exj, ex2);
+                        }
+                        const float rr = (tc + rho) + e2;
+                        if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                    }
+                    bits |= cand ? (1ull << a) : 0ull;
                     certh = certh || (dd < tab_wcert[w * 16 + a]);           // inscribed balls overlap
                 }
             }
@@ -3266,8 +3305,18 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     o.vcl = B.add(vp_cls.data(), sizeof(int) * P);
     // float32 tables + error slack of the conservative broadphase.  Position error of a float32 chain sweep is below
     // (joints + 2) * 16 ulp(float) * reach; the slack is 50x that, never below 1e-4 of the reach.
+    // local bounding box of every hull (centre, half extents rounded outwards): the hull midphase culls against it
+    std::vector<double> hull_obb(6 * (size_t)(H > 0 ? H : 1), 0.0);
+    for (int h = 0; h < H; ++h) {
+        const double* v = d->hull_verts + 3 * (size_t)d->hull_vert_begin[h];
+        const int n = d->hull_vert_begin[h + 1] - d->hull_vert_begin[h];
+        double lo[3] = {v[0], v[1], v[2]}, hi[3] = {v[0], v[1], v[2]};
+        for (int k = 1; k < n; ++k)
+            for (int j = 0; j < 3; ++j) { lo[j] = std::min(lo[j], v[3 * k + j]); hi[j] = std::max(hi[j], v[3 * k + j]); }
+        for (int j = 0; j < 3; ++j) { hull_obb[6 * h + j] = 0.5 * (lo[j] + hi[j]); hull_obb[6 * h + 3 + j] = 0.5 * (hi[j] - lo[j]) * (1.0 + 1e-12) + 1e-300; }
+    }
     std::vector<float> ftab;
-    int f_trans, f_slide, f_base, f_tl, f_wc;
+    int f_trans, f_slide, f_base, f_tl, f_wc, f_wobb = 0;
     double reach = 0.0;
     {
         for (int k = 0; k < J; ++k) for (int e = 0; e < 27; ++e) ftab.push_back((float)d->joint_rot[27 * k + e]);
@@ -3301,6 +3350,12 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
             for (int e = 0; e < 3; ++e) n2 += ws_core[18 * w + e] * ws_core[18 * w + e];
             if (std::sqrt(n2) > reach) reach = std::sqrt(n2);          // world coordinates enter the differences too
         }
+        f_wobb = (int)ftab.size();
+        for (int w = 0; w < W; ++w)
+            for (int e = 0; e < 6; ++e) {
+                const double v = ws_hull[w] >= 0 ? hull_obb[6 * (size_t)ws_hull[w] + e] : 0.0;
+                ftab.push_back(e < 3 ? (float)v : (float)v * (1.0f + 2.4e-7f));          // half extents rounded up
+            }
         if (ftab.empty()) ftab.push_back(0.0f);
     }
     o.ft = B.add(ftab.data(), sizeof(float) * ftab.size());
@@ -3331,7 +3386,17 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     }
     const size_t o_rin = B.add(rs_in.data(), sizeof(double) * S);
     const size_t o_win = B.add(ws_in.data(), sizeof(double) * W);
-    const size_t o_hv = B.add(d->hull_verts, sizeof(double) * 3 * (size_t)(H > 0 ? d->hull_vert_begin[H] : 0));
+    // hull vertices, each hull's list preceded by its local bounding box (centre, half extents): 6 + 3 n doubles per hull
+    std::vector<double> hull_blob;
+    std::vector<size_t> hull_off(H > 0 ? H : 1, 0);           // offset (in doubles) of hull h's first vertex inside hull_blob
+    for (int h = 0; h < H; ++h) {
+        const double* v = d->hull_verts + 3 * (size_t)d->hull_vert_begin[h];
+        const int n = d->hull_vert_begin[h + 1] - d->hull_vert_begin[h];
+        hull_blob.insert(hull_blob.end(), &hull_obb[6 * h], &hull_obb[6 * h] + 6);
+        hull_off[h] = hull_blob.size();
+        hull_blob.insert(hull_blob.end(), v, v + 3 * (size_t)n);
+    }
+    const size_t o_hv = B.add(hull_blob.data(), sizeof(double) * hull_blob.size());
     const size_t o_hp = B.add(d->hull_planes, sizeof(double) * 4 * (size_t)(H > 0 ? d->hull_face_begin[H] : 0));
     B.bytes.resize((B.bytes.size() + 255) & ~size_t(255));
 
@@ -3342,7 +3407,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     {
         auto patch = [&](size_t slot, int h) {
             HullRef r;
-            r.hv = reinterpret_cast<const double*>(static_cast<const char*>(dev) + o_hv) + 3 * (size_t)d->hull_vert_begin[h];
+            r.hv = reinterpret_cast<const double*>(static_cast<const char*>(dev) + o_hv) + hull_off[h];
             r.hp = reinterpret_cast<const double*>(static_cast<const char*>(dev) + o_hp) + 4 * (size_t)d->hull_face_begin[h];
             r.hn = d->hull_vert_begin[h + 1] - d->hull_vert_begin[h];
             r.hf = d->hull_face_begin[h + 1] - d->hull_face_begin[h];
@@ -3389,7 +3454,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.vp_cls = reinterpret_cast<const int*>(base + o.vcl);
     for (int c = 0; c < 4; ++c) { m.cls_base[c] = cls_base[c]; m.cls_groups[c] = cls_groups[c] > 0 ? cls_groups[c] : 1; }
     m.f_tab = reinterpret_cast<const float*>(base + o.ft);
-    m.f_trans = f_trans; m.f_slide = f_slide; m.f_base = f_base; m.f_tl = f_tl; m.f_wc = f_wc;
+    m.f_trans = f_trans; m.f_slide = f_slide; m.f_base = f_base; m.f_tl = f_tl; m.f_wc = f_wc; m.f_wobb = f_wobb;
     // relative slack: 50 x the float32 error bound (joints + 2) * 16 ulp of a chain sweep; the kernel multiplies it by the
     // larger of the static reach and the configuration's own largest coordinate (prismatic travel is unbounded here)
     {

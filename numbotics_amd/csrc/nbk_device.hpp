@@ -104,7 +104,8 @@ NBK_DEV void nbk_sincos(double x, double& s, double& c) {
 
 // ---- convex cores ------------------------------------------------------------------------------
 // shape = core (+) ball(margin):  sphere = point, capsule = segment, box, cylinder (axis = local z), hull (vertex list)
-struct HullRef { const double* hv; const double* hp; int hn; int hf; };   // vertices [hn][3], face planes [hf][4] (n, d), local frame
+struct HullRef { const double* hv; const double* hp; int hn; int hf; };   // vertices [hn][3], face planes [hf][4] (n, d), local frame;
+                                                                         // hv[-6..-1] = the hull's local bounding box: centre (3), half extents (3)
 struct Core {
     int kind;            // wave-uniform
     double c[3];
@@ -146,7 +147,20 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
             const int hn = s.hull.hn;
             double best = -NBK_INF;
             int bi = 0;
-            for (int k = 0; k < hn; ++k) {
+            // four vertices per trip: their twelve loads are issued together (per-lane loads in k_narrow, where the lanes of a wave
+            // hold different hulls), the comparisons stay in vertex order
+            int k = 0;
+            for (; k + 4 <= hn; k += 4) {
+                double vx[4], vy[4], vz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { vx[u] = hv[3 * (k + u)]; vy[u] = hv[3 * (k + u) + 1]; vz[u] = hv[3 * (k + u) + 2]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double pr = NBK_FMA(vz[u], dl2, NBK_FMA(vy[u], dl1, vx[u] * dl0));
+                    if (pr > best) { best = pr; bi = k + u; }
+                }
+            }
+            for (; k < hn; ++k) {
                 const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
                 if (pr > best) { best = pr; bi = k; }
             }
@@ -940,9 +954,30 @@ NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rh
     return (hc - hw) < t;
 }
 
+// Cull for hull cores (device only; it never changes a verdict): the other core lies in the ball (c, rho), the hull inside its local
+// bounding box, so a centre farther than tc + rho from that box means a core distance of at least tc -- free.  The comparison keeps a
+// 1e-9 relative margin so that it can never contradict what the GJK iteration of the oracle decides in its last digits.
+NBK_DEV bool hull_box_far(const double* c, double rho, const Core& H, double tc) {
+    const double* ob = H.hull.hv - 6;
+    double d[3];
+    sub3(c, H.c, d);
+    double d2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double ex = __builtin_fabs(dot3(d, H.ax[j]) - ob[j]) - ob[3 + j];
+        if (ex > 0.0) d2 = NBK_FMA(ex, ex, d2);
+    }
+    const double r = NBK_FMA(tc + rho, 1e-9, tc + rho);
+    return d2 >= r * r;
+}
+
 // steps 4-5 of the predicate up to (not including) GJK: 0 = free, 1 = colliding, -1 = the GJK predicate decides.
 // A/Bc already in canonical order, neither is a plane.
 NBK_DEV int cores_collide_pre(const Core& A, const Core& Bc, double tc) {
+    if (tc >= 0.0) {
+        if (A.kind == K_HULL && hull_box_far(Bc.c, Bc.rho, A, tc)) return 0;
+        if (Bc.kind == K_HULL && hull_box_far(A.c, A.rho, Bc, tc)) return 0;
+    }
     // midphase for box cores: the other core's centre against the exact box (no square roots)
     if (A.kind == K_BOX || Bc.kind == K_BOX) {
         const bool b_is_box = Bc.kind == K_BOX;
