@@ -19,6 +19,8 @@ HBM).  Beside it, all timed with HIP events on the launch stream, median and min
   records               BASELINE config 5: M = 10 071 samples, every pair's distance / contact points / normal / (P,7) row,
                         on the primitive scene and on the mesh scene (compound-mesh collision shapes)
   config4_shard         one GPU's share of config 4's 1e7 batch (1.25e6 q)
+  two_streams           the headline steps issued alternately on two HIP streams (independent batches): throughput with the
+                        narrowphase of one step under the broadphase of the next
   fk_roofline, fk_all_links_roofline, jacobian_roofline   the HBM-bound kernels of the path
   cpu_baseline          the CPU oracle (a port of the same algorithm, oracle/) on this box's host cores, bounded sample
 """
@@ -263,6 +265,27 @@ def main():
                              "pageable": dict(e_page, configs_per_s=B / (e_page["median_ms"] * 1e-3)),
                              "h2d_bytes": B * 8.0 * chain.dof, "d2h_bytes": n_words * 8.0}
         del pin_q, dq, page_q
+
+        # ---- the same steps issued round-robin on two HIP streams (independent batches, as a planner has them): every stream has
+        # its own scratch set inside the descriptor, so the latency-bound narrowphase of one step runs under the issue-bound
+        # broadphase of the next.  Wall clock over 40 steps; NOT the headline `value`, which stays one stream, one step at a time.
+        sts = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for st_ in sts:
+            st_.wait_stream(torch.cuda.current_stream())
+
+        def issue(n):
+            for i in range(n):
+                with torch.cuda.stream(sts[i & 1]):
+                    dev.validity(qs[i % N_ROTATE], 0.0, packed=True)
+        issue(4)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        issue(40)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t2
+        out["two_streams"] = {"what": "40 validity steps (same batches as the headline) issued alternately on two HIP streams; wall clock, "
+                              "barrier-free region bracketed by synchronize", "ms_per_step": dt2 / 40 * 1e3, "configs_per_s": 40 * B / dt2,
+                              "vs_one_stream": (40 * B / dt2) / (B / (kern["median_ms"] * 1e-3))}
 
         # ---- the HBM-bound kernels of the path, rotating inputs ---------------------------------------------------------
         it = [0]
