@@ -128,6 +128,11 @@ struct StreamWs {
     long long ecap_edges; unsigned long long ecap_samples;
     unsigned long long* stats;      // [4] pinned + mapped: samples needed by the last finished edge call, edges served by the overflow kernel
     unsigned long long* stats_dev;  // device alias of `stats`
+    // tile pipelining of batches of several tiles: odd tiles run on `aux_stream` with the scratch set `aux` (forked from / joined
+    // to the caller's stream with events), so the latency-bound narrowphase of one tile overlaps the issue-bound broadphase of the next
+    hipStream_t aux_stream;
+    hipEvent_t ev_fork, ev_join;
+    StreamWs* aux;
 };
 }  // namespace nbk
 
@@ -3505,6 +3510,9 @@ void nbk_model_destroy(nbk_model* m) {
         if (w->ws) (void)hipFree(w->ws);
         if (w->ews) (void)hipFree(w->ews);
         if (w->stats) (void)hipHostFree(w->stats);
+        if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+        if (w->ev_join) (void)hipEventDestroy(w->ev_join);
+        if (w->aux_stream) (void)hipStreamDestroy(w->aux_stream);
         delete w;
     }
     if (m->scalar_q) (void)hipHostFree(m->scalar_q);
@@ -3551,12 +3559,13 @@ struct Options {
     long long jac_two_sweep;        // NBK_JAC_TWO_SWEEP: the general Jacobian kernel also for short paths
     long long closest_brute;        // NBK_CLOSEST_BRUTE: every pair instead of branch-and-bound
     long long narrow_parts_max;     // NBK_NARROW_PARTS_MAX: cap of the narrowphase workgroups per sub-queue
+    long long pipeline_tiles;       // NBK_PIPELINE_TILES: batches of >= 2 x 2^20 configurations run their tiles alternately on two streams (default 1)
     long long queue_budget;         // NBK_QUEUE_BUDGET: bytes the item queues of one tile may take (default 1 GiB); tests shrink it to force
                                     // the overflow path (k_validity_redo)
 };
 static long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 static Options g_opt = {env_ll("NBK_TWO_KERNEL_MIN_B", 1), env_ll("NBK_EDGE_BATCH_MIN_E", 1), env_ll("NBK_NO_REG_BROAD", 0),
-                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_QUEUE_BUDGET", 1ll << 30)};
+                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_PIPELINE_TILES", 1), env_ll("NBK_QUEUE_BUDGET", 1ll << 30)};
 
 // diagnostic (not part of include/nbk.h): set one of the switches above by name; returns NBK_ERR_INVALID for an unknown name
 extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
@@ -3564,7 +3573,7 @@ extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
     struct { const char* n; long long* v; } tab[] = {
         {"two_kernel_min_b", &g_opt.two_kernel_min_b}, {"edge_batch_min_e", &g_opt.edge_batch_min_e}, {"no_reg_broad", &g_opt.no_reg_broad},
         {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute},
-        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}};
+        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}, {"pipeline_tiles", &g_opt.pipeline_tiles}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) { *t.v = (long long)value; return NBK_OK; }
     return NBK_ERR_INVALID;
 }
@@ -3809,6 +3818,7 @@ static StreamWs* stream_ws(nbk_model* mm, hipStream_t st) {
     StreamWs* w = new StreamWs();
     w->stream = st; w->ws = nullptr; w->ws_bytes = 0; w->ready = false; w->thr = 0.0; w->epoch = 0;
     w->ews = nullptr; w->ews_bytes = 0; w->ecap_edges = 0; w->ecap_samples = 0; w->stats = nullptr; w->stats_dev = nullptr;
+    w->aux_stream = nullptr; w->ev_fork = nullptr; w->ev_join = nullptr; w->aux = nullptr;
     mm->wss.push_back(w);
     return w;
 }
@@ -3828,13 +3838,21 @@ static int32_t grow_scratch(hipStream_t st, void*& buf, size_t& have, size_t nee
 // queue fits the workspace.  `iw`: the workspace is this stream's own set and keeps state between calls (tables, counter epoch);
 // nullptr: caller-owned workspace, or a call being captured into a graph -- self-contained: every call prepares its tables
 // and clears its counters itself.
+static const int64_t PIPE_TILE = int64_t(1) << 20;               // tile size of pipelined batches
+static inline bool pipelined(const nbk_model* m, int64_t B) { return g_opt.pipeline_tiles != 0 && m->parked_ok && B >= 2 * PIPE_TILE; }
+static inline int64_t call_tile(const nbk_model* m, const PairCounts& pc, int64_t B, bool pipe) {
+    const int64_t t = tile_configs(m, pc, B);
+    return pipe && t > PIPE_TILE ? PIPE_TILE : t;
+}
+
+// `pipe` (the library's own scratch only): odd tiles run on iw0->aux_stream with the scratch set iw0->aux
 static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
-                                      uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw) {
-    unsigned long long* count_set0 = static_cast<unsigned long long*>(workspace);
-    unsigned long long* count = count_set0;
-    unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_header(m));
-    const bool internal = iw != nullptr;
-    const int64_t tile = tile_configs(m, pc, B);
+                                      uint8_t* mask_bytes, void* workspace0, hipStream_t st0, StreamWs* iw0, bool pipe) {
+    const int64_t tile = call_tile(m, pc, B, pipe);
+    if (pipe) {
+        NBK_HIP(hipEventRecord(iw0->ev_fork, st0));                          // the odd tiles' inputs are whatever the caller's stream has produced
+        NBK_HIP(hipStreamWaitEvent(iw0->aux_stream, iw0->ev_fork, 0));
+    }
     // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
     // distance predicate only, else the build with both
     bool any_zero = false, any_nonzero = false, any_negative = false;
@@ -3846,7 +3864,16 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
     const int S = m->d.n_rshapes;
     const bool use_reg = S <= 16 && (!g_opt.no_reg_broad || !m->lds_broad_ok);
     const bool f32 = !g_opt.f64_broad || broad_reg_lds(m, S <= 8 ? 8 : (S <= 12 ? 12 : 16)) > 160 * 1024;   // the float64 form keeps its tables in LDS
-    for (int64_t b0 = 0; b0 < B; b0 += tile) {
+    int tile_no = 0;
+    for (int64_t b0 = 0; b0 < B; b0 += tile, ++tile_no) {
+        const bool odd = pipe && (tile_no & 1);
+        StreamWs* iw = odd ? iw0->aux : iw0;
+        hipStream_t st = odd ? iw0->aux_stream : st0;
+        void* workspace = odd ? iw0->aux->ws : workspace0;
+        const bool internal = iw != nullptr;
+        unsigned long long* count_set0 = static_cast<unsigned long long*>(workspace);
+        unsigned long long* count = count_set0;
+        unsigned long long* items = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + ws_header(m));
         const int64_t nb = (B - b0) < tile ? (B - b0) : tile;
         const unsigned nblk = blocks_for(nb);
         // a sub-queue takes one kind class of the blocks of one group (every 64th block): worst case all pairs of that class
@@ -3915,18 +3942,43 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
             NBK_HIP(hipGetLastError());
         }
     }
+    if (pipe) {
+        NBK_HIP(hipEventRecord(iw0->ev_join, iw0->aux_stream));              // the caller's stream continues when the odd tiles are done too
+        NBK_HIP(hipStreamWaitEvent(st0, iw0->ev_join, 0));
+    }
     return NBK_OK;
 }
 
 static int32_t launch_two_kernel(const nbk_model* m, const PairCounts& pc, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
-                                 uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw = nullptr) {
-    const int32_t rc = launch_two_kernel_impl(m, pc, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, iw);
-    if (rc != NBK_OK && iw != nullptr) iw->ready = false;      // whatever state the queues are in: start over
+                                 uint8_t* mask_bytes, void* workspace, hipStream_t st, StreamWs* iw = nullptr, bool pipe = false) {
+    const int32_t rc = launch_two_kernel_impl(m, pc, es, q, B, threshold, mask_bits, mask_bytes, workspace, st, iw, pipe);
+    if (rc != NBK_OK && iw != nullptr) { iw->ready = false; if (iw->aux) iw->aux->ready = false; }      // whatever state the queues are in: start over
     return rc;
 }
 
-static int64_t two_kernel_workspace_bytes(const nbk_model* m, const PairCounts& pc, int64_t B) {
-    const int64_t nblk = (tile_configs(m, pc, B) + WAVE - 1) / WAVE;
+// the second stream, its events and its scratch set of a pipelined call (created on first use; never while capturing)
+static int32_t pipe_setup(nbk_model* mm, const nbk_model* m, const PairCounts& pc, StreamWs* w, int64_t B, hipStream_t st) {
+    if (w->aux_stream == nullptr) {
+        NBK_HIP(hipStreamCreateWithFlags(&w->aux_stream, hipStreamNonBlocking));
+        NBK_HIP(hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming));
+        NBK_HIP(hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming));
+        w->aux = stream_ws(mm, w->aux_stream);
+        if (w->aux == nullptr) return NBK_ERR_ALLOC;
+    }
+    const int64_t nblk = (call_tile(m, pc, B, true) + WAVE - 1) / WAVE;
+    const size_t need = ws_header(m) + 8 * (size_t)NSUB * (size_t)tile_queue_cap(m, pc, (unsigned long long)nblk);
+    if (w->aux->ws_bytes < need) {
+        w->aux->ready = false;
+        const int32_t rc = grow_scratch(w->aux_stream, w->aux->ws, w->aux->ws_bytes, need, "hipMalloc(workspace, second stream)");
+        if (rc != NBK_OK) return rc;
+        NBK_HIP(hipMemsetAsync(static_cast<char*>(w->aux->ws) + ws_tables(m), 0, WS_FLAGS, w->aux_stream));
+    }
+    (void)st;
+    return NBK_OK;
+}
+
+static int64_t two_kernel_workspace_bytes(const nbk_model* m, const PairCounts& pc, int64_t B, bool pipe = false) {
+    const int64_t nblk = (call_tile(m, pc, B, pipe) + WAVE - 1) / WAVE;
     return (int64_t)ws_header(m) + 8 * (int64_t)NSUB * (int64_t)tile_queue_cap(m, pc, (unsigned long long)nblk);
 }
 
@@ -3965,12 +4017,13 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
     // the library's own scratch is sized for the pairs that are within reach at THIS threshold (obstacle-rich scenes: most world
     // shapes are out of the arm's reach for good)
     const PairCounts pc = reachable_pairs(m, threshold);
-    const int64_t need = two_kernel_workspace_bytes(m, pc, B);
     hipStream_t st = (hipStream_t)stream;
+    const bool capturing = stream_capturing(st);
+    const bool pipe = pipelined(m, B) && !capturing;
+    const int64_t need = two_kernel_workspace_bytes(m, pc, B, pipe);
     StreamWs* w = stream_ws(const_cast<nbk_model*>(m), st);
     if (w == nullptr) { snprintf(g_err, sizeof(g_err), "more than 64 streams use this descriptor's internal workspaces: pass your own (nbk_validity_batch_ws)"); return NBK_ERR_ALLOC; }
     std::lock_guard<std::mutex> lock(w->mu);
-    const bool capturing = stream_capturing(st);
     if (w->ws_bytes < (size_t)need) {
         if (capturing) {
             snprintf(g_err, sizeof(g_err), "graph capture: this stream's internal workspace is not allocated yet -- run the call once "
@@ -3985,7 +4038,8 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
     // a captured call must be self-contained (it is replayed out of order with the host-side state): prepare + clear inside
     // the graph, and the next direct call starts from scratch as well
     if (capturing) w->ready = false;
-    return launch_two_kernel(m, pc, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w);
+    if (pipe) { const int32_t rc = pipe_setup(const_cast<nbk_model*>(m), m, pc, w, B, st); if (rc != NBK_OK) return rc; }
+    return launch_two_kernel(m, pc, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w, pipe);
 }
 
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
@@ -4144,7 +4198,9 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
     NBK_HIP(hipGetLastError());
     EdgeSrc es{starts, goals, plan, map, offs + E, 0, nullptr};
     if (capturing) w->ready = false;
-    const int32_t rc = launch_two_kernel(m, pc, es, nullptr, (int64_t)cap, threshold, words, nullptr, w->ws, st, capturing ? nullptr : w);
+    const bool pipe = pipelined(m, (int64_t)cap) && !capturing;
+    if (pipe) { const int32_t rp = pipe_setup(const_cast<nbk_model*>(m), m, pc, w, (int64_t)cap, st); if (rp != NBK_OK) return rp; }
+    const int32_t rc = launch_two_kernel(m, pc, es, nullptr, (int64_t)cap, threshold, words, nullptr, w->ws, st, capturing ? nullptr : w, pipe);
     if (rc != NBK_OK) return rc;
     hipLaunchKernelGGL(k_edge_reduce, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, words, ovf, valid, w->stats_dev);
     NBK_HIP(hipGetLastError());
