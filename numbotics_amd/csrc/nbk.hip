@@ -163,6 +163,8 @@ struct nbk_model {
     std::mutex scalar_mu;
     double* scalar_q;         // [n_q] host-pinned, read by the kernel through its device alias
     unsigned long long* scalar_out;
+    double* scalar_q_dev;     // device aliases of the two pinned buffers
+    unsigned long long* scalar_out_dev;
     hipStream_t scalar_stream;
 };
 
@@ -2541,7 +2543,12 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     sweep_and_park(m, lds_q, lds_s, lds_fr, lane, lds_jz);
     double best = NBK_INF;
     int bi = -1;
-    for (int p = 0; p < m.n_pairs; ++p) {
+    // MODE >= 1: gridDim.y workgroups share the pairs of a block of configurations (each sweeps the tree itself and takes every
+    // gridDim.y-th ... contiguous slice of the pair list): small batches such as IRIS' 10 071 samples would otherwise put one
+    // wave per 64 samples on a 1 024-SIMD chip and walk 44 GJK distances one after the other
+    const int p_lo = (MODE == 0) ? 0 : (int)(((long long)m.n_pairs * blockIdx.y) / gridDim.y);
+    const int p_hi = (MODE == 0) ? m.n_pairs : (int)(((long long)m.n_pairs * (blockIdx.y + 1)) / gridDim.y);
+    for (int p = p_lo; p < p_hi; ++p) {
         Core A, Bc;
         load_pair(m, lds_s, p, lane, A, Bc);
         double wit[9];
@@ -3927,6 +3934,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         // workgroups per sub-queue: one 64-item chunk each at a few survivors per configuration; more chunks are strided over
         unsigned parts = 4u * nblk / NSUB;
         { const unsigned pmax = g_opt.narrow_parts_max > 0 ? (unsigned)g_opt.narrow_parts_max : 16u; parts = parts < 4u ? 4u : parts; parts = parts > pmax ? pmax : parts; }
+        if (nblk <= 4u) parts = 1u;                      // a handful of configurations (the scalar calls): 256 workgroups are plenty
         if (!any_nonzero)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero && !any_negative)
@@ -4042,6 +4050,16 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
     return launch_two_kernel(m, pc, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w, pipe);
 }
 
+// workgroups that share the pair list of one block of configurations in the per-pair distance kernels: enough to put ~8 waves on
+// every SIMD pair of the chip when the batch alone would not (at most one group per pair)
+static inline unsigned pair_groups(const nbk_model* m, int64_t B) {
+    const long long nblk = (B + WAVE - 1) / WAVE;
+    long long g = (4096 + nblk - 1) / nblk;
+    if (g > m->n_pairs) g = m->n_pairs;
+    if (g > 64) g = 64;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || min_dist == nullptr))) return NBK_ERR_INVALID;
     NBK_DEVICE(m);
@@ -4064,10 +4082,10 @@ int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B,
     if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     if (witness != nullptr)
-        hipLaunchKernelGGL(k_distances<2>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
+        hipLaunchKernelGGL(k_distances<2>, dim3(blocks_for(B), pair_groups(m, B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
                            (int32_t*)nullptr, witness);
     else
-        hipLaunchKernelGGL(k_distances<1>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
+        hipLaunchKernelGGL(k_distances<1>, dim3(blocks_for(B), pair_groups(m, B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
                            (int32_t*)nullptr, (double*)nullptr);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
@@ -4081,7 +4099,7 @@ int32_t nbk_proximity_jacobian_batch(const nbk_model* m, const double* q, int64_
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     const size_t lds = collide_lds(m) + sizeof(double) * WAVE * 6 * (size_t)m->n_joints;
     if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_distances<3>, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, q, B, dist, (int32_t*)nullptr,
+    hipLaunchKernelGGL(k_distances<3>, dim3(blocks_for(B), pair_groups(m, B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, q, B, dist, (int32_t*)nullptr,
                        witness, jrows);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
@@ -4222,6 +4240,8 @@ static int32_t scalar_setup(nbk_model* mm) {
     NBK_HIP(hipHostMalloc((void**)&mm->scalar_q, nd * sizeof(double), hipHostMallocMapped));
     NBK_HIP(hipHostMalloc((void**)&mm->scalar_out, 8 * sizeof(unsigned long long), hipHostMallocMapped));
     NBK_HIP(hipStreamCreateWithFlags(&mm->scalar_stream, hipStreamNonBlocking));
+    NBK_HIP(hipHostGetDevicePointer((void**)&mm->scalar_q_dev, mm->scalar_q, 0));
+    NBK_HIP(hipHostGetDevicePointer((void**)&mm->scalar_out_dev, mm->scalar_out, 0));
     return NBK_OK;
 }
 
@@ -4232,10 +4252,8 @@ int32_t nbk_validity_scalar_host(const nbk_model* m, const double* q, double thr
     std::lock_guard<std::mutex> lock(mm->scalar_mu);
     { const int32_t rc = scalar_setup(mm); if (rc != NBK_OK) return rc; }
     memcpy(mm->scalar_q, q, sizeof(double) * (size_t)m->n_q);
-    double* dq = nullptr;
-    uint64_t* dout = nullptr;
-    NBK_HIP(hipHostGetDevicePointer((void**)&dq, mm->scalar_q, 0));
-    NBK_HIP(hipHostGetDevicePointer((void**)&dout, mm->scalar_out, 0));
+    double* dq = mm->scalar_q_dev;
+    uint64_t* dout = reinterpret_cast<uint64_t*>(mm->scalar_out_dev);
     mm->scalar_out[0] = 0ull;
     const int32_t rc = nbk_validity_batch(m, dq, 1, threshold, dout, nullptr, mm->scalar_stream);
     if (rc != NBK_OK) return rc;
@@ -4257,10 +4275,8 @@ int32_t nbk_edge_validity_scalar_host(const nbk_model* m, const double* start, c
     memcpy(h, start, sizeof(double) * nq);
     memcpy(h + nq, goal, sizeof(double) * nq);
     h[3 * nq] = dist;
-    double* d = nullptr;
-    unsigned long long* dout = nullptr;
-    NBK_HIP(hipHostGetDevicePointer((void**)&d, mm->scalar_q, 0));
-    NBK_HIP(hipHostGetDevicePointer((void**)&dout, mm->scalar_out, 0));
+    double* d = mm->scalar_q_dev;
+    unsigned long long* dout = mm->scalar_out_dev;
     const bool has_dist = dist >= 0.0 || dist != dist;      // a negative value = "Euclidean norm" (a NaN length is a given length)
     const int32_t rc = nbk_edge_validity_batch(m, d, d + nq, has_dist ? d + 3 * nq : nullptr, 1, resolution, max_distance, mode, threshold,
                                                reinterpret_cast<uint8_t*>(dout), d + 2 * nq, reinterpret_cast<int32_t*>(dout + 1), mm->scalar_stream);
