@@ -3567,12 +3567,13 @@ struct Options {
     long long closest_brute;        // NBK_CLOSEST_BRUTE: every pair instead of branch-and-bound
     long long narrow_parts_max;     // NBK_NARROW_PARTS_MAX: cap of the narrowphase workgroups per sub-queue
     long long pipeline_tiles;       // NBK_PIPELINE_TILES: batches of >= 2 x 2^20 configurations run their tiles alternately on two streams (default 1)
+    long long pipe_tile;            // NBK_PIPE_TILE: configurations per tile of a pipelined batch (default 2^20)
     long long queue_budget;         // NBK_QUEUE_BUDGET: bytes the item queues of one tile may take (default 1 GiB); tests shrink it to force
                                     // the overflow path (k_validity_redo)
 };
 static long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 static Options g_opt = {env_ll("NBK_TWO_KERNEL_MIN_B", 1), env_ll("NBK_EDGE_BATCH_MIN_E", 1), env_ll("NBK_NO_REG_BROAD", 0),
-                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_PIPELINE_TILES", 1), env_ll("NBK_QUEUE_BUDGET", 1ll << 30)};
+                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_PIPELINE_TILES", 1), env_ll("NBK_PIPE_TILE", 1ll << 20), env_ll("NBK_QUEUE_BUDGET", 1ll << 30)};
 
 // diagnostic (not part of include/nbk.h): set one of the switches above by name; returns NBK_ERR_INVALID for an unknown name
 extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
@@ -3580,7 +3581,7 @@ extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
     struct { const char* n; long long* v; } tab[] = {
         {"two_kernel_min_b", &g_opt.two_kernel_min_b}, {"edge_batch_min_e", &g_opt.edge_batch_min_e}, {"no_reg_broad", &g_opt.no_reg_broad},
         {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute},
-        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}, {"pipeline_tiles", &g_opt.pipeline_tiles}};
+        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}, {"pipeline_tiles", &g_opt.pipeline_tiles}, {"pipe_tile", &g_opt.pipe_tile}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) { *t.v = (long long)value; return NBK_OK; }
     return NBK_ERR_INVALID;
 }
@@ -3845,7 +3846,7 @@ static int32_t grow_scratch(hipStream_t st, void*& buf, size_t& have, size_t nee
 // queue fits the workspace.  `iw`: the workspace is this stream's own set and keeps state between calls (tables, counter epoch);
 // nullptr: caller-owned workspace, or a call being captured into a graph -- self-contained: every call prepares its tables
 // and clears its counters itself.
-static const int64_t PIPE_TILE = int64_t(1) << 20;               // tile size of pipelined batches
+#define PIPE_TILE (g_opt.pipe_tile > 0 ? (int64_t)g_opt.pipe_tile : (int64_t(1) << 20))      // tile size of pipelined batches (NBK_PIPE_TILE)
 static inline bool pipelined(const nbk_model* m, int64_t B) { return g_opt.pipeline_tiles != 0 && m->parked_ok && B >= 2 * PIPE_TILE; }
 static inline int64_t call_tile(const nbk_model* m, const PairCounts& pc, int64_t B, bool pipe) {
     const int64_t t = tile_configs(m, pc, B);
