@@ -79,7 +79,7 @@ def main():
     from numbotics_amd.physics import World
     from numbotics_amd.physics.world import _reset_worlds
     from numbotics_amd.scenes import build_scene, sample_q
-    from numbotics_amd.parallel import shard_bounds, allgather_mask_words
+    from numbotics_amd.parallel import shard_bounds, shard_words, allgather_mask_words
     from numbotics_amd.csrc.build import source_digest
 
     World()
@@ -94,7 +94,9 @@ def main():
     qs = [torch.from_numpy(q_host).cuda()] + [torch.from_numpy(sample_q(chain, B, seed=1 + rank + 1000 * i)).cuda() for i in range(1, N_ROTATE)]
     q = qs[0]
     n_words = (B + 63) // 64
-    gathered = torch.zeros((world * n_words,), dtype=torch.int64, device="cuda") if world > 1 else None
+    g_words = shard_words(total, world)          # every rank contributes this many words (a short last shard is padded with zero bits)
+    gathered = torch.zeros((world * g_words,), dtype=torch.int64, device="cuda") if world > 1 else None
+    padded = torch.zeros((g_words,), dtype=torch.int64, device="cuda") if world > 1 and g_words != n_words else None
     # N > 1: the all-gather of a step's packed mask (a latency-bound 125 KB-per-rank message) runs on RCCL's stream while the
     # next step's kernels run; two receive buffers, a buffer is waited for before it is reused and all of them before the
     # clock stops.  gloo (control-flow rehearsal only) and --sync-gather keep the serial form.
@@ -105,6 +107,9 @@ def main():
     state = {"overlap": overlap}
 
     def gather(words):
+        if padded is not None:                   # unequal shards (strong scaling of a batch that does not divide evenly)
+            padded[:n_words].copy_(words)
+            words = padded
         if not state["overlap"]:
             allgather_mask_words(words, gathered)
             return
