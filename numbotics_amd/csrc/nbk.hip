@@ -2050,8 +2050,8 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                                 g = __builtin_fminf(g, wc[12 + j] - axj);
                             }
                             if (!inside) {
-                                const float rr = (tc + rho) + e2;
-                                if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                                const float rr = ((tc > 0.0f ? tc : 0.0f) + rho) + e2;   // tc < 0: disjoint is enough (device-only cull)
+                                if (ex2 >= rr * rr * up) cand = false;
                                 if (cand && ex2 < tab_wcin[w * 16 + a]) ch = true;
                             } else if (cand && g > -tc + e2 && rs > e2 && dd * up < (rs - e2) * (rs - e2)) {
                                 ch = true;
@@ -2078,8 +2078,8 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                                 const float exj = __builtin_fabsf(xj) - ob[3 + j];
                                 if (exj > 0.0f) ex2 = __builtin_fmaf(exj, exj, ex2);
                             }
-                            const float rr = (tc + rho) + e2;
-                            if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                            const float rr = ((tc > 0.0f ? tc : 0.0f) + rho) + e2;       // tc < 0: disjoint is enough (device-only cull)
+                            if (ex2 >= rr * rr * up) cand = false;
                         }
                         c[a] = cand;
                     }
@@ -2182,8 +2182,8 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                         }
                         if (!inside) {
                             // outside by more than the slack in every float64 reading: free when far enough (tc >= 0 only)
-                            const float rr = (tc + rho) + e2;
-                            if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                            const float rr = ((tc > 0.0f ? tc : 0.0f) + rho) + e2;       // tc < 0: disjoint is enough (device-only cull)
+                            if (ex2 >= rr * rr * up) cand = false;
                             // the centre is closer to the box than the radius of the ball inscribed in the shape: certain hit
                             if (cand && ex2 < tab_wcin[w * 16 + a]) certh = true;
                         } else if (cand && g > -tc + e2 && rs > e2 && dd * up < (rs - e2) * (rs - e2)) {
@@ -2213,8 +2213,8 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                             const float exj = __builtin_fabsf(xj) - ob[3 + j];
                             if (exj > 0.0f) ex2 = __builtin_fmaf(exj, exj, ex2);
                         }
-                        const float rr = (tc + rho) + e2;
-                        if (tc >= 0.0f && ex2 >= rr * rr * up) cand = false;
+                        const float rr = ((tc > 0.0f ? tc : 0.0f) + rho) + e2;
+                        if (ex2 >= rr * rr * up) cand = false;
                     }
                     bits |= cand ? (1ull << a) : 0ull;
                     certh = certh || (dd < tab_wcert[w * 16 + a]);           // inscribed balls overlap

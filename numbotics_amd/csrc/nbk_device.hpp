@@ -967,16 +967,34 @@ NBK_DEV bool hull_box_far(const double* c, double rho, const Core& H, double tc)
         const double ex = __builtin_fabs(dot3(d, H.ax[j]) - ob[j]) - ob[3 + j];
         if (ex > 0.0) d2 = NBK_FMA(ex, ex, d2);
     }
-    const double r = NBK_FMA(tc + rho, 1e-9, tc + rho);
+    const double r0 = (tc > 0.0 ? tc : 0.0) + rho;      // a non-positive threshold: disjoint is enough
+    const double r = NBK_FMA(r0, 1e-9, r0);
     return d2 >= r * r;
+}
+
+// The same cull for box cores at NEGATIVE thresholds (device only; for tc >= 0 the predicate's own midphase does it, bit for bit like
+// the oracle): the other core's centre farther than its bounding radius from the box => the cores are disjoint => free.
+NBK_DEV bool box_far_negative(const double* c, double rho, const Core& bx) {
+    double d[3];
+    sub3(c, bx.c, d);
+    double d2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double ex = __builtin_fabs(dot3(d, bx.ax[j])) - bx.h[j];
+        if (ex > 0.0) d2 = NBK_FMA(ex, ex, d2);
+    }
+    const double r = NBK_FMA(rho, 1e-9, rho);
+    return d2 >= r * r && d2 > 0.0;
 }
 
 // steps 4-5 of the predicate up to (not including) GJK: 0 = free, 1 = colliding, -1 = the GJK predicate decides.
 // A/Bc already in canonical order, neither is a plane.
 NBK_DEV int cores_collide_pre(const Core& A, const Core& Bc, double tc) {
-    if (tc >= 0.0) {
-        if (A.kind == K_HULL && hull_box_far(Bc.c, Bc.rho, A, tc)) return 0;
-        if (Bc.kind == K_HULL && hull_box_far(A.c, A.rho, Bc, tc)) return 0;
+    if (A.kind == K_HULL && hull_box_far(Bc.c, Bc.rho, A, tc)) return 0;
+    if (Bc.kind == K_HULL && hull_box_far(A.c, A.rho, Bc, tc)) return 0;
+    if (tc < 0.0) {
+        if (A.kind == K_BOX && box_far_negative(Bc.c, Bc.rho, A)) return 0;
+        if (Bc.kind == K_BOX && box_far_negative(A.c, A.rho, Bc)) return 0;
     }
     // midphase for box cores: the other core's centre against the exact box (no square roots)
     if (A.kind == K_BOX || Bc.kind == K_BOX) {
