@@ -161,6 +161,9 @@ class Chain:
         if q.shape != (self._dof,):
             raise ValueError(f"configuration must have {self._dof} elements")
         self._configuration = q.copy()
+        w = _world.WORLD_INSTANCES.get(self._world_name)
+        if w is not None:
+            w._touch()          # another arm's scene holds this chain's links as obstacles at this configuration
 
 
 class GraphChain(Chain):

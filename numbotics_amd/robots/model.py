@@ -209,6 +209,30 @@ def _shape_records(cs, owner_pose_local: np.ndarray, hulls: HullTable, bullet_ma
     return [_shape_record(cs, owner_pose_local, bullet_margins)]
 
 
+def chain_link_poses(chain) -> dict:
+    """World poses {link name: 4x4} of every link of ``chain`` at ``chain.configuration`` -- how the links of ANOTHER chain enter an
+    arm's scene: as static obstacles (upstream: ``Arm.collision_pairs`` pairs every link with every link of the other chains in the
+    world, robots/arm.py:226-243, and Bullet holds those bodies at their current joint state).  Host-side scene set-up in NumPy (a
+    few dozen 4x4 products, once per compile), same joint formula as the kernels: L = M0 - cos(q) M1 + sin(q) M2."""
+    kin = compile_kinematics(chain)
+    q = np.asarray(chain.configuration, dtype=np.float64)
+    base = np.vstack([kin.base_pose.reshape(3, 4), [0.0, 0.0, 0.0, 1.0]])
+    frames = []
+    for k in range(kin.n_joints):
+        M = kin.joint_rot[k].reshape(3, 3, 3)
+        qk = q[kin.joint_qidx[k]]
+        X = np.eye(4)
+        if kin.joint_type[k] == JT_REVOLUTE:
+            X[:3, :3] = M[0] - np.cos(qk) * M[1] + np.sin(qk) * M[2]
+            X[:3, 3] = kin.joint_trans[k]
+        else:
+            X[:3, :3] = M[0]
+            X[:3, 3] = kin.joint_trans[k] + qk * kin.joint_slide[k]
+        parent = base if kin.joint_parent[k] < 0 else frames[kin.joint_parent[k]]
+        frames.append(parent @ X)
+    return {name: (base if fr.joint < 0 else frames[fr.joint]) @ fr.local for name, fr in kin.frames.items()}
+
+
 def _shape_record(cs, owner_pose_local: np.ndarray, bullet_margins: bool = False):
     """(type, 3x4 pose in the owner frame, params[4]) for one primitive CollisionShape."""
     info = cs._shape_info
@@ -314,6 +338,7 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True, bull
     S = len(r_type)
     objects, w_type, w_pose, w_param, w_obj = [], [], [], [], []
     shapes_of_obj = {}
+    other_poses = {}                     # id(other chain) -> {link name: world pose at its current configuration}
     pa, pb = [], []
     def in_chain(x):
         return isinstance(x, Link) and x._body_id == chain._pyb_id and x._world_name == chain._world_name
@@ -347,8 +372,35 @@ def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True, bull
                 for sb in shapes_of_obj[key]:
                     pa.append(sa)
                     pb.append(S + sb)
+        elif isinstance(b, Link):
+            # a link of another chain in the same world: a static obstacle at that chain's current configuration
+            key = id(b)
+            if key not in shapes_of_obj:
+                other = next((o for o in chain.world.objects() if not isinstance(o, PhysicsObject) and getattr(o, '_pyb_id', None) == b._body_id), None)
+                if other is None:
+                    raise ValueError(f"link {b._name} belongs to no chain of this world")
+                if id(other) not in other_poses:
+                    other_poses[id(other)] = chain_link_poses(other)
+                ids = []
+                for cs in (b._collision_shapes if compound else [b._collision_shape]):
+                    if cs.shape == Shape.EMPTY:
+                        continue
+                    for t, T, p in _shape_records(cs, other_poses[id(other)][b._name], hulls, bullet_margins):
+                        if t == SH_PLANE:
+                            raise ValueError("a PLANE cannot be a robot link shape")
+                        ids.append(len(w_type))
+                        w_type.append(t)
+                        w_pose.append(_T34(T))
+                        w_param.append(p)
+                        w_obj.append(len(objects))
+                objects.append(b)
+                shapes_of_obj[key] = ids
+            for sa in shapes_of_link[ia]:
+                for sb in shapes_of_obj[key]:
+                    pa.append(sa)
+                    pb.append(S + sb)
         else:
-            raise NotImplementedError("collision pairs against links of another chain are not built yet")
+            raise ValueError(f"cannot pair a link with {type(b).__name__}")
     # stable order: by subject shape, then target (the device loops shape-A-major)
     if pa:
         order = np.lexsort((np.array(pb), np.array(pa)))

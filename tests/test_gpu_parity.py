@@ -1355,3 +1355,34 @@ def test_bullet_margin_mode(fresh_world, scene, torch_cuda):
     arm.bullet_margins = False
     assert (arm.scene_model().rshape_param[:, 3] == 0).all()
     assert np.array_equal(arm.in_collision(q[:5000]), Oracle(arm.scene_model()).validity(q[:5000]))
+
+
+def test_two_arms_in_one_world(fresh_world, torch_cuda):
+    """The links of another chain are obstacles of this arm's scene (robots/arm.py:226-243): masks, distances and closest pair bit
+    for bit against the oracle, and the scene follows the other arm's configuration."""
+    from numbotics_amd.physics import GraphChain
+    from numbotics_amd.robots import Arm
+    from numbotics_amd.scenes import KINOVA_URDF, KINOVA_MESH_URDF, apply_rrt_script_removals
+    c1 = GraphChain.from_urdf(KINOVA_URDF)
+    c2 = GraphChain.from_urdf(KINOVA_MESH_URDF)                              # the neighbour carries mesh links
+    T = np.eye(4); T[:3, 3] = [0.55, 0.25, 0.0]
+    c2.base_pose = T
+    c2.configuration = np.array([0.3, 0.8, -0.5, 1.2, 0.1, -0.7, 0.4])
+    arm = Arm(c1)
+    apply_rrt_script_removals(arm)
+    q = sample_q(c1, 20000, seed=12)
+    masks = []
+    for conf in (c2.configuration, np.array([-1.0, 1.3, 0.4, 1.8, -0.3, 0.9, 0.0])):
+        c2.configuration = conf
+        sm = arm.scene_model()
+        assert sm.n_wshapes == 11 and (sm.wshape_type == 5).sum() == 10
+        orc = Oracle(sm)
+        for thr in (0.0, 0.02):
+            assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr, nthreads=8)), thr
+        assert_bitwise(arm.pair_distances(q[:1000]), orc.pair_distances(q[:1000]), "two-arm distances")
+        dmin, idx = arm.closest_distance(q[:2000])
+        dref, iref = orc.closest(q[:2000])
+        assert_bitwise(dmin, dref, "two-arm closest")
+        assert np.array_equal(idx, iref)
+        masks.append(orc.validity(q, 0.0, nthreads=8))
+    assert (masks[0] != masks[1]).any() and 0.02 < masks[0].mean() < 0.9

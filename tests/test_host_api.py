@@ -182,3 +182,39 @@ def test_discrete_connector_scalar_contract_vs_golden(g5, golden_meta):
             assert np.array_equal(out, ret) and out is not g
         checked += 1
     assert checked > 300
+
+
+def test_links_of_another_chain_are_obstacles(fresh_world):
+    """Upstream pairs every link of the arm with every link of the OTHER chains in its world (robots/arm.py:226-243; Bullet holds
+    those bodies at their current joint state).  Here they enter the scene as static shapes at that chain's ``configuration``."""
+    from numbotics_amd.physics import GraphChain
+    from numbotics_amd.robots import Arm
+    from numbotics_amd.robots.model import chain_link_poses
+    from numbotics_amd.scenes import KINOVA_URDF, apply_rrt_script_removals
+    from oracle.cpu_oracle import Oracle
+    c1 = GraphChain.from_urdf(KINOVA_URDF)
+    c2 = GraphChain.from_urdf(KINOVA_URDF)
+    T = np.eye(4); T[:3, 3] = [0.5, 0.3, 0.0]
+    c2.base_pose = T
+    c2.configuration = np.array([0.3, 0.8, -0.5, 1.2, 0.1, -0.7, 0.4])
+    arm = Arm(c1)
+    apply_rrt_script_removals(arm)
+    n_self = len(arm.self_collision_pairs())
+    sm = arm.scene_model()
+    assert sm.n_rshapes == 11 and sm.n_wshapes == 11                      # the other arm's 11 primitives
+    assert sm.n_pairs == 121 + (sm.n_pairs - 121) and sm.n_pairs > 121    # 11 x 11 cross pairs + the arm's own self pairs
+    assert len(arm.collision_pairs()) == n_self + 10 * 16                   # 10 shaped links x all 16 links of the other chain
+    # the other chain's link poses = its own FK at its configuration
+    poses = chain_link_poses(c2)
+    orc2 = Oracle(Arm(c2)._kin)
+    for name in ("tool_frame", "forearm_link", "bracelet_link", "base_link"):
+        assert np.abs(poses[name] - orc2.fk(c2.configuration[None], name)[0]).max() < 1e-14
+    q = np.random.default_rng(3).uniform(-2, 2, (2000, 7))
+    m0 = Oracle(sm).validity(q)
+    rev = c1.world._revision
+    c2.configuration = np.zeros(7)                                         # moving the other arm invalidates the compiled scene
+    assert c1.world._revision > rev
+    m1 = Oracle(arm.scene_model()).validity(q)
+    assert 0 < m0.sum() < 2000 and (m0 != m1).any()
+    # pairs against the other chain can be removed by name like any other
+    arm.remove_collision_pair('tool_frame', c2._links[3])
