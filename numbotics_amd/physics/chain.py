@@ -62,6 +62,12 @@ class Link:
             raise ValueError("Link is not registered in the world")
         return f'{self._world_name}:{self._body_name}:{self._name}'
 
+    def distance_to(self, target, max_distance: float = np.inf):
+        """Closest-point records against ``target`` (an object, a link or a chain) at the bodies' current state, one per shape
+        pair, ``distance <= max_distance`` (reference: the ``getClosestPoints`` wrapper of this class)."""
+        from .proximity import body_distances
+        return body_distances(self, target, max_distance)
+
     @property
     def index(self):
         return self._index
@@ -150,6 +156,11 @@ class Chain:
         w = _world.WORLD_INSTANCES.get(self._world_name)
         if w is not None:
             w._touch()
+
+    def distance_to(self, target, max_distance: float = np.inf):
+        """Every link of this chain (at ``configuration``) against ``target`` (reference: physics/chain.py:944-969)."""
+        from .proximity import body_distances
+        return body_distances(self, target, max_distance)
 
     @property
     def configuration(self):

@@ -79,6 +79,12 @@ class PhysicsObject:
         self._pose[:3, 3] = np.asarray(p, dtype=np.float64)
         self._moved()
 
+    def distance_to(self, target, max_distance: float = np.inf):
+        """Closest-point records against ``target`` (an object, a link or a chain) at the bodies' current state, one per shape
+        pair, ``distance <= max_distance`` (reference: the ``getClosestPoints`` wrapper of this class)."""
+        from .proximity import body_distances
+        return body_distances(self, target, max_distance)
+
     @property
     def orientation(self):
         return self._pose[:3, :3].copy()

@@ -1,0 +1,87 @@
+"""Body-level closest-point queries: ``PhysicsObject.distance_to`` / ``Link.distance_to`` / ``Chain.distance_to``
+(reference: numbotics/physics/object.py:325-349, numbotics/physics/chain.py:352-379, :944-969 -- thin wrappers over
+``pybullet.getClosestPoints(bodyA, bodyB, max_distance[, linkIndexA / linkIndexB])`` at the bodies' CURRENT state).
+
+Here: the subject's shapes (a chain's links at its ``configuration``) become the shapes of a zero-joint device model, the
+target's shapes its world shapes, and one ``nbk_pair_distances_batch`` launch yields every (subject shape, target shape)
+record; ``Proximity`` fields and the ``distance <= max_distance`` filter as upstream.  Distance values are this build's
+(parity with Bullet unpinned).  No CPU path: a GPU is required, as for every other query.
+"""
+import numpy as np
+
+from numbotics_amd.utils import Shape
+from .collision import Proximity
+
+
+def _owner_chain(link):
+    from .chain import Chain
+    for o in link.world.objects():
+        if isinstance(o, Chain) and o._pyb_id == link._body_id:
+            return o
+    raise ValueError(f"link {link._name} belongs to no chain of its world")
+
+
+def _static_shapes(entity):
+    """[(object the Proximity names, CollisionShape, 4x4 world pose of its owner frame)]"""
+    from .chain import Chain, Link
+    from .object import PhysicsObject
+    from numbotics_amd.robots.model import chain_link_poses
+    if isinstance(entity, PhysicsObject):
+        cs = entity._collision_shape
+        return [] if cs.shape == Shape.EMPTY else [(entity, cs, entity.pose)]
+    if isinstance(entity, Link):
+        poses = chain_link_poses(_owner_chain(entity))
+        return [(entity, cs, poses[entity._name]) for cs in entity._collision_shapes if cs.shape != Shape.EMPTY]
+    if isinstance(entity, Chain):
+        poses = chain_link_poses(entity)
+        return [(l, cs, poses[l._name]) for l in entity._links for cs in l._collision_shapes if cs.shape != Shape.EMPTY]
+    raise ValueError(f"cannot measure distances of {type(entity).__name__}")
+
+
+def body_distances(subject, target, max_distance: float = np.inf, bullet_margins: bool = False):
+    """``list[Proximity]`` between every shape of ``subject`` and every shape of ``target`` with distance <= max_distance."""
+    from numbotics_amd.robots.model import (KinematicModel, SceneModel, HullTable, _shape_records, _T34, SH_PLANE)
+    from numbotics_amd.engine import DeviceModel
+    subj, targ = _static_shapes(subject), _static_shapes(target)
+    if not subj or not targ:
+        return []
+    hulls = HullTable()
+
+    def records(shapes):
+        out = []
+        for obj, cs, pose in shapes:
+            for t, T, p in _shape_records(cs, pose, hulls, bullet_margins):
+                out.append((obj, t, T, p))
+        return out
+    rs, ws = records(subj), records(targ)
+    swapped = any(t == SH_PLANE for _, t, _, _ in rs)
+    if swapped:                                   # a plane can only be the second shape of a pair: measure the other way round
+        if any(t == SH_PLANE for _, t, _, _ in ws):
+            raise ValueError("the distance between two planes is not defined")
+        rs, ws = ws, rs
+    S, W = len(rs), len(ws)
+    z = np.zeros
+    kin = KinematicModel(n_q=1, joint_parent=z(0, dtype=np.int32), joint_type=z(0, dtype=np.int32), joint_qidx=z(0, dtype=np.int32),
+                         joint_offset=z((0, 12)), joint_axis=z((0, 3)), joint_rot=z((0, 27)), joint_trans=z((0, 3)), joint_slide=z((0, 3)),
+                         base_pose=_T34(np.eye(4)))
+    hvb, hv, hfb, hp = hulls.arrays()
+    pa = np.repeat(np.arange(S, dtype=np.int32), W)
+    pb = np.tile(np.arange(S, S + W, dtype=np.int32), S)
+    sm = SceneModel(kin=kin, rshape_frame=np.full(S, -1, dtype=np.int32), rshape_type=np.array([r[1] for r in rs], dtype=np.int32),
+                    rshape_local=np.array([_T34(r[2]) for r in rs]).reshape(S, 12), rshape_param=np.array([r[3] for r in rs]).reshape(S, 4),
+                    rshape_link=z(S, dtype=np.int32), wshape_type=np.array([w[1] for w in ws], dtype=np.int32),
+                    wshape_pose=np.array([_T34(w[2]) for w in ws]).reshape(W, 12), wshape_param=np.array([w[3] for w in ws]).reshape(W, 4),
+                    wshape_obj=z(W, dtype=np.int32), pair_a=pa, pair_b=pb,
+                    hull_vert_begin=hvb, hull_verts=hv, hull_face_begin=hfb, hull_planes=hp)
+    dist, wit = DeviceModel(sm).pair_distances(np.zeros((1, 1)), witness=True)
+    out = []
+    for p in range(S * W):
+        d = float(dist[0, p])
+        if not d <= max_distance:
+            continue
+        a, b = rs[pa[p]][0], ws[pb[p] - S][0]
+        ps, pt, n = wit[0, p, 0:3].copy(), wit[0, p, 3:6].copy(), wit[0, p, 6:9].copy()
+        if swapped:
+            a, b, ps, pt, n = b, a, pt, ps, -n
+        out.append(Proximity(subject=a, target=b, position_on_subject=ps, position_on_target=pt, normal_target_to_subject=n, distance=d))
+    return out

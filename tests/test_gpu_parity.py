@@ -1386,3 +1386,44 @@ def test_two_arms_in_one_world(fresh_world, torch_cuda):
         assert np.array_equal(idx, iref)
         masks.append(orc.validity(q, 0.0, nthreads=8))
     assert (masks[0] != masks[1]).any() and 0.02 < masks[0].mean() < 0.9
+
+
+def test_body_level_distance_to(fresh_world, torch_cuda):
+    """``PhysicsObject.distance_to`` / ``Link.distance_to`` / ``Chain.distance_to`` (reference: object.py:325-349, chain.py:352-379,
+    :944-969) -- closest-point records at the bodies' current state -- agree with the oracle's shape-pair distances and with the
+    arm-level records."""
+    from numbotics_amd.physics import GraphChain, Cube, Sphere, Plane, Mesh
+    from numbotics_amd.robots import Arm
+    from numbotics_amd.scenes import KINOVA_URDF, MESH_DIR
+    from oracle.cpu_oracle import shape_distance
+    import os
+    cube = Cube(0.0, 0.2, position=np.array([0.6, 0.1, 0.3]))
+    ball = Sphere(0.0, 0.1, position=np.array([0.6, 0.1, 0.9]))
+    floor = Plane(0.0, np.array([0.0, 0.0, 1.0]), position=np.array([0.0, 0.0, -0.05]))
+    rock = Mesh(0.0, os.path.join(MESH_DIR, "rock.obj"), position=np.array([-0.5, 0.2, 0.4]))
+    # object vs object
+    (p,) = cube.distance_to(ball)
+    d, wa, wb, n, _ = shape_distance(2, cube.pose, [0.2, 0.2, 0.2, 0.0], 0, ball.pose, [0.1, 0, 0, 0])
+    assert p.subject is cube and p.target is ball and p.distance == d
+    assert np.array_equal(p.position_on_subject, wa) and np.array_equal(p.position_on_target, wb) and np.array_equal(p.normal_target_to_subject, n)
+    assert abs(p.distance - 0.3) < 1e-12
+    assert cube.distance_to(ball, max_distance=0.1) == []
+    # a plane as the subject: measured the other way round, fields swapped
+    (pp,) = floor.distance_to(ball)
+    (pq,) = ball.distance_to(floor)
+    assert pp.distance == pq.distance and abs(pp.distance - 0.85) < 1e-12
+    assert np.array_equal(pp.position_on_subject, pq.position_on_target) and np.array_equal(pp.normal_target_to_subject, -pq.normal_target_to_subject)
+    assert len(rock.distance_to(cube)) == 1 and rock.distance_to(cube)[0].distance > 0
+    # chain / link vs object at the chain's configuration == the arm-level records at that q
+    chain = GraphChain.from_urdf(KINOVA_URDF)
+    q = np.array([0.4, 0.9, -0.3, 1.1, 0.2, -0.6, 0.1])
+    chain.configuration = q
+    arm = Arm(chain)
+    prox = chain.distance_to(cube)
+    ref = arm.distance_to(q, cube)
+    assert len(prox) == len(ref) == 11
+    assert sorted(round(p.distance, 12) for p in prox) == sorted(round(p.distance, 12) for p in ref)
+    link = next(l for l in chain._links if l._name == "forearm_link")
+    (pl,) = link.distance_to(cube)
+    assert pl.subject is link and any(abs(pl.distance - r.distance) < 1e-12 and r.subject._name == "forearm_link" for r in ref)
+    assert len(chain.distance_to(rock, max_distance=0.5)) <= 11
