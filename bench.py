@@ -18,6 +18,7 @@ HBM).  Beside it, all timed with HIP events on the launch stream, median and min
   edge_roofline         BASELINE config 3: E = 1e5 DiscreteConnector edges, resolution 0.01, 8-cube ring
   records               BASELINE config 5: M = 10 071 samples, every pair's distance / contact points / normal / (P,7) row,
                         on the primitive scene and on the mesh scene (compound-mesh collision shapes)
+  config1_plumbing      config 1: tool_frame FK of 1024 q, CPU oracle rate beside one device call
   config4_shard         one GPU's share of config 4's 1e7 batch (1.25e6 q)
   two_streams           the headline steps issued alternately on two HIP streams (independent batches): throughput with the
                         narrowphase of one step under the broadphase of the next
@@ -319,6 +320,24 @@ def main():
         out["jacobian_roofline"] = dict(jc, bound="hbm", kernel="k_jacobian_reg", achieved=jac_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                                         frac=jac_gbs / HBM_PEAK_GBS, traffic=None, kernel_ms=jc["median_ms"], algorithmic_bytes=jac_bytes,
                                         jacobians_per_s=B / (jc["median_ms"] * 1e-3), algorithmic_bytes_per_config=56.0 * chain.dof)
+
+        # ---- config 1 (plumbing): tool_frame FK of 1024 random q -- the CPU oracle's rate beside one device call ----------------
+        q1h = sample_q(chain, 1024, seed=11, margin=0.1)
+        from oracle.cpu_oracle import Oracle as _Orc
+        ok1 = _Orc(arm._kin)
+        t1 = time.perf_counter()
+        n1 = 0
+        while time.perf_counter() - t1 < 0.2:
+            T_cpu = ok1.fk(q1h, "tool_frame")
+            n1 += 1
+        cpu1 = 1024 * n1 / (time.perf_counter() - t1)
+        q1d = torch.from_numpy(q1h).cuda()
+        g1 = timed(lambda: arm.forward_kinematics(q1d, "tool_frame"), reps=20)
+        T_gpu = arm.forward_kinematics(q1d, "tool_frame").cpu().numpy()
+        out["config1_plumbing"] = {"what": "BASELINE config 1: Kinova tool_frame FK, 1024 random q (q ~ U(lower + 0.1, upper - 0.1), _test_arm.py:58)",
+                                   "cpu_oracle_poses_per_s": cpu1, "cpu_kind": "port (oracle/nbk_oracle.c orc_fk, one thread)",
+                                   "gpu_call_median_ms": g1["median_ms"], "gpu_poses_per_s": 1024 / (g1["median_ms"] * 1e-3),
+                                   "gpu_equals_oracle_bitwise": bool(np.array_equal(T_gpu, T_cpu))}
 
         # ---- config 4's per-GPU shard: 1e7 / 8 = 1.25e6 q ----------------------------------------------------------------
         if not strong and B == 1_000_000:
