@@ -18,7 +18,9 @@
  *     wait for that stream's earlier work.  Captured before the scratch exists they return
  *     NBK_ERR_UNSUPPORTED (run the call once outside the capture, or use nbk_validity_batch_ws, whose
  *     scratch is the caller's); captured after, they are self-contained graph nodes.  The *_host
- *     conveniences synchronise by definition;
+ *     conveniences synchronise by definition.  Batches of 2^21 configurations or more (and edge batches of that many samples)
+ *     run every other 2^20-configuration tile on a second, library-owned stream forked from and joined to `stream` with
+ *     events -- the call still begins after, and completes before, its neighbours in `stream`'s order;
  *   - every compute call must be made with the descriptor's device current (hipSetDevice):
  *     NBK_ERR_INVALID otherwise;
  *   - float64 everywhere (the reference computes in float64); q is row-major (B, n_q);
