@@ -18,12 +18,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
 
 
 def source_digest() -> str:
-    """sha256 (first 16 hex digits) of the kernel sources: profiles record it, bench.py refuses counters of another build."""
+    """sha256 (first 16 hex digits) of what determines the device code -- nbk.hip, nbk_device.hpp and the compiler flags:
+    profiles record it, bench.py refuses counters of another build.  (The C header and this script only declare / drive.)"""
     import hashlib
     h = hashlib.sha256()
-    for name in SOURCES:
+    for name in ("nbk.hip", "nbk_device.hpp"):
         with open(os.path.join(HERE, name), "rb") as f:
             h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
     return h.hexdigest()[:16]
 
 
