@@ -167,3 +167,41 @@ def test_hull_descriptor_errors_at_the_c_boundary(fresh_world, torch_cuda):
     with pytest.raises(_lib.NbkError):
         DeviceModel(bad)
     assert _lib.load().nbk_abi_version() == 2
+
+
+def test_large_and_degenerate_hulls(fresh_world, torch_cuda, tmp_path):
+    """A 600-vertex hull (brute-force support over every vertex, as Bullet's btConvexHullShape does) and a FLAT mesh (a hull without
+    face planes: support function only) as obstacles: masks at three thresholds, distances and witnesses bit-exact vs the oracle."""
+    from numbotics_amd.physics import GraphChain, Mesh, Sphere
+    from numbotics_amd.robots import Arm
+    from numbotics_amd.scenes import KINOVA_URDF, apply_rrt_script_removals
+    from numbotics_amd.utils.mesh import write_obj, hull_faces
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(600, 3))
+    pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * [0.25, 0.2, 0.15]          # every point is a hull vertex
+    V, F = hull_faces(pts)
+    big = write_obj(str(tmp_path / "big.obj"), [("ellipsoid", V, F)])
+    flat = tmp_path / "flat.obj"
+    flat.write_text("v 0 0 0\nv 0.4 0 0\nv 0.4 0.3 0\nv 0 0.3 0\nv 0.2 0.15 0\nf 1 2 3 4\n")
+    chain = GraphChain.from_urdf(KINOVA_URDF)
+    arm = Arm(chain)
+    apply_rrt_script_removals(arm)
+    obs = [Mesh(0.0, big, position=np.array([0.55, 0.2, 0.5])),
+           Mesh(0.0, str(flat), position=np.array([-0.5, -0.1, 0.45]), collision_margin=0.01),
+           Sphere(0.0, 0.1, position=np.array([0.0, 0.6, 0.6]))]
+    sm = arm.scene_model()
+    assert sm.n_hulls == 2 and sm.hull_vert_begin[1] == 600 and sm.hull_face_begin[2] == sm.hull_face_begin[1]      # the flat hull has no planes
+    orc = Oracle(sm)
+    q = sample_q(chain, 12000, seed=9)
+    for thr in (0.0, 0.02, -0.004):
+        ref = orc.validity(q, thr, nthreads=8)
+        assert np.array_equal(arm.in_collision(q, thr), ref), thr
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:1500], thr), ref[:1500]), (thr, "fused")
+    assert 0.02 < orc.validity(q, nthreads=8).mean() < 0.9
+    _, dev = arm._scene_device()
+    d, w = dev.pair_distances(q[:400], witness=True)
+    dr, wr = orc.pair_distances(q[:400], witness=True)
+    assert_bitwise(d, dr, "big / flat hull distances")
+    assert_bitwise(w, wr, "big / flat hull witnesses")
+    assert len(obs) == 3
