@@ -141,13 +141,14 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # one HIP event per step boundary on the launch stream: step k runs between ev[k] and ev[k + 1]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev[0].record()
     for k in range(args.steps):
-        ev[k][0].record()
         words = dev.validity(qs[k % N_ROTATE], 0.0, packed=True)
-        ev[k][1].record()
+        ev[k + 1].record()
         if world > 1:
             gather(words)
     drain()
@@ -159,7 +160,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    step_ms = [a.elapsed_time(b) for a, b in ev]
+    step_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
     kern = stats_ms(step_ms)
     kern_ms = kern["mean_ms"]
     last_q_host = q_host if (args.steps - 1) % N_ROTATE == 0 else sample_q(chain, B, seed=1 + rank + 1000 * ((args.steps - 1) % N_ROTATE))
