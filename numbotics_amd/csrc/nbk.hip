@@ -2450,6 +2450,17 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
+#ifdef NBK_PROTO_INFL
+            } else if constexpr (MODE == 3) {
+                GjkBool gb;
+                gjkb_init(gb, A, Bc);
+                while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
+                    if (have) {
+                        const int r = gjkb_step<true>(gb, A, Bc, tc);
+                        if (r != 0) { if (r >= 2) mark_hit(b, mask_bits, mask_bytes); if (r == 3) atomicAdd(&g_narrow_prof[11], 1ull); have = false; }
+                    }
+                }
+#endif
             } else if constexpr (MODE == 2 || MODE == 3) {
                 GjkPred g;
                 gjk_pred_init(g, A, Bc);

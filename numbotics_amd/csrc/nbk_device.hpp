@@ -130,9 +130,15 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
         case K_CYL: {
             const double du = dot3(d, s.ax[2]);
             const double sg = du >= 0.0 ? s.h[0] : -s.h[0];
-            double w[3];
-            axpy3(-du, s.ax[2], d, w);
-            axpy3(-dot3(w, s.ax[2]), s.ax[2], w, w);   // second Gram-Schmidt pass (d almost axial: see oracle)
+            // w = (u.u) d - (d.u) u, twice: perpendicular to the axis whatever its length (see the oracle: a joint axis given to
+            // five digits leaves the link rotations orthonormal to 1e-6 only)
+            const double uu = dot3(s.ax[2], s.ax[2]);
+            double w[3], t[3];
+            t[0] = uu * d[0]; t[1] = uu * d[1]; t[2] = uu * d[2];
+            axpy3(-du, s.ax[2], t, w);
+            const double wu = dot3(w, s.ax[2]);
+            t[0] = uu * w[0]; t[1] = uu * w[1]; t[2] = uu * w[2];
+            axpy3(-wu, s.ax[2], t, w);
             const double ww = dot3(w, w);
             axpy3(sg, s.ax[2], s.c, o);
             if (ww > 0.0) {
@@ -553,6 +559,9 @@ NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
 
 // ---- boolean GJK (the predicate for tc == 0): mirrors gjk_intersect of the oracle ------------------------------
 constexpr int GJKB_MAXIT = 32;
+#ifndef GJKB_INFL_MAXIT
+#define GJKB_INFL_MAXIT 12
+#endif
 struct GjkBool { double p[3][3]; int n; double d[3]; int it; };   // p[0] oldest; at most 3 points are kept between steps
 
 NBK_DEV void mink_support(const Core& A, const Core& Bc, const double* d, double* w) {
@@ -609,10 +618,15 @@ NBK_DEV void gjkb_init(GjkBool& g, const Core& A, const Core& Bc) {
     for (int i = 0; i < 3; ++i) { g.p[i][0] = 0.0; g.p[i][1] = 0.0; g.p[i][2] = 0.0; }
 }
 // one iteration: 0 = continue, 1 = free, 2 = intersecting
-NBK_DEV int gjkb_step(GjkBool& g, const Core& A, const Core& Bc) {
-    if (g.it >= GJKB_MAXIT) return 2;
+template <bool INFL = false>
+NBK_DEV int gjkb_step(GjkBool& g, const Core& A, const Core& Bc, double tc = 0.0) {
+    if (g.it >= (INFL ? GJKB_INFL_MAXIT : GJKB_MAXIT)) return INFL ? 3 : 2;
     double a[3];
     mink_support(A, Bc, g.d, a);
+    if constexpr (INFL) {
+        const double k = tc / nbk_sqrt(dot3(g.d, g.d));
+        axpy3(k, g.d, a, a);
+    }
     if (dot3(a, g.d) < 0.0) return 1;
     g.it += 1;
     if (g.n == 0) {

@@ -182,6 +182,11 @@ class Oracle:
         lib().orc_validity(C.byref(self._m), _p(q), C.c_int64(B), C.c_double(threshold), _p(mask), C.c_int32(nthreads))
         return mask.astype(bool)
 
+    def pair_trace(self, q, pair, threshold=0.0):
+        """Diagnostic: print the walk of both predicates for one pair of one configuration (stderr)."""
+        q = _f64(q, (-1, self.n_q))
+        lib().orc_pair_trace(C.byref(self._m), _p(q), C.c_int32(pair), C.c_double(threshold))
+
     def edge_validity(self, starts, goals, resolution, max_distance, mode="connect", threshold=0.0, dist=None,
                       nthreads=1):
         s = _f64(starts, (-1, self.n_q))

@@ -10,6 +10,7 @@
 #include <float.h>
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -401,14 +402,23 @@ static void core_support(const core_t *s, const double *d, double *o) {
             axpy3(sg, s->ax[2], s->c, o);
         } break;
         case K_CYL: {
+            /* radial direction = d minus its axial part, taken twice and WITHOUT assuming a unit axis:
+             *   w = (u.u) d - (d.u) u   is perpendicular to u whatever the length of u (a joint axis given to five digits
+             *   leaves link rotations orthonormal to 1e-6 only, robots/helpers.py:43-55 uses the axis as given), and the second
+             *   pass removes what the rounding of the first leaves when d is almost axial.  With a plain d - (d.u)u an
+             *   exactly axial d kept an axial remainder of (1 - u.u)^2 |d| that the normalisation below blew up to O(rad):
+             *   a "support point" off the cylinder, and a boolean walk that enclosed the origin of a separated pair
+             *   (fuzz seeds 70350, 70503). */
             const double *u = s->ax[2];
             const double du = dot3(d, u);
+            const double uu = dot3(u, u);
             const double sg = du >= 0.0 ? s->h[0] : -s->h[0];
-            double w[3];
-            axpy3(-du, u, d, w);
-            axpy3(-dot3(w, u), u, w, w);   /* second Gram-Schmidt pass: when d is almost axial the first
-                                              difference cancels and w would keep an axial component that
-                                              the normalisation below blows up to O(rad) */
+            double w[3], t[3];
+            t[0] = uu * d[0]; t[1] = uu * d[1]; t[2] = uu * d[2];
+            axpy3(-du, u, t, w);
+            const double wu = dot3(w, u);
+            t[0] = uu * w[0]; t[1] = uu * w[1]; t[2] = uu * w[2];
+            axpy3(-wu, u, t, w);
             const double ww = dot3(w, w);
             axpy3(sg, u, s->c, o);
             if (ww > 0.0) {
@@ -1146,6 +1156,50 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     g_stat_gjk++;
     if (tc == 0.0) return gjk_intersect(A, Bc);      /* pure intersection test: the boolean walk */
     return gjk_collides(A, Bc, tc);
+}
+
+/* diagnostic: one pair of one configuration, with the walk of either predicate printed (tools/fuzz_repro.py) */
+static void robot_cores(const orc_model *m, const double *q, xf_t *frames, core_t *rc);
+static core_t *build_world_cores(const orc_model *m);
+int orc_pair_trace(const orc_model *m, const double *q, int32_t p, double thr) {
+    core_t *wc = build_world_cores(m);
+    xf_t *frames = (xf_t *)malloc(sizeof(xf_t) * (size_t)(m->n_joints > 0 ? m->n_joints : 1));
+    core_t *rc = (core_t *)malloc(sizeof(core_t) * (size_t)(m->n_rshapes > 0 ? m->n_rshapes : 1));
+    robot_cores(m, q, frames, rc);
+    const int a = m->pair_a[p], b = m->pair_b[p];
+    const core_t *A = &rc[a], *Bc = b < m->n_rshapes ? &rc[b] : &wc[b - m->n_rshapes];
+    if (A->kind > Bc->kind) { const core_t *t = A; A = Bc; Bc = t; }
+    const double tc = (thr + A->margin) + Bc->margin;
+    fprintf(stderr, "pair %d: kinds %d %d  tc %.17g  margins %.6g %.6g  rad %.6g %.6g  h %.6g/%.6g/%.6g %.6g/%.6g/%.6g  hull verts %d %d\n", p, A->kind, Bc->kind, tc,
+            A->margin, Bc->margin, A->rad, Bc->rad, A->h[0], A->h[1], A->h[2], Bc->h[0], Bc->h[1], Bc->h[2], A->hn, Bc->hn);
+    for (int side = 0; side < 2; ++side) {
+        const core_t *s = side ? Bc : A;
+        fprintf(stderr, "  core%d c %.17g %.17g %.17g\n", side, s->c[0], s->c[1], s->c[2]);
+        for (int j = 0; j < 3; ++j) fprintf(stderr, "  core%d ax%d %.17g %.17g %.17g\n", side, j, s->ax[j][0], s->ax[j][1], s->ax[j][2]);
+        for (int k = 0; k < s->hn; ++k) fprintf(stderr, "  core%d v %.17g %.17g %.17g\n", side, s->hv[3 * k], s->hv[3 * k + 1], s->hv[3 * k + 2]);
+        for (int k = 0; k < s->hf; ++k) fprintf(stderr, "  core%d f %.17g %.17g %.17g %.17g\n", side, s->hp[4 * k], s->hp[4 * k + 1], s->hp[4 * k + 2], s->hp[4 * k + 3]);
+    }
+    double wit[9];
+    int it = 0;
+    const double dcan = cores_distance(A, Bc, wit, &it);
+    fprintf(stderr, "  distance (canonical order) %.17g after %d iterations\n", dcan, it);
+    fprintf(stderr, "  distance (swapped)         %.17g\n", cores_distance(Bc, A, wit, &it));
+    gjkb_t g;
+    gjkb_init(&g, A, Bc);
+    for (;;) {
+        double w[3];
+        mink_support(A, Bc, g.d, w);
+        fprintf(stderr, "  bool it %2d n %d d (%.6g %.6g %.6g) w (%.9g %.9g %.9g) w.d %.6g\n", g.it, g.n, g.d[0], g.d[1], g.d[2], w[0], w[1], w[2], dot3(w, g.d));
+        { double sa[3], sb[3], nd[3] = {-g.d[0], -g.d[1], -g.d[2]}; core_support(A, g.d, sa); core_support(Bc, nd, sb);
+          double r[3]; sub3(sa, A->c, r);
+          fprintf(stderr, "      d %.17g %.17g %.17g | sa-c axial %.17g |sa-c| %.17g  d.u %.17g\n", g.d[0], g.d[1], g.d[2], dot3(r, A->ax[2]), sqrt(dot3(r, r)), dot3(g.d, A->ax[2])); }
+        for (int i = 0; i < g.n; ++i) fprintf(stderr, "      p%d (%.9g %.9g %.9g)\n", i, g.p[i][0], g.p[i][1], g.p[i][2]);
+        const int r = gjkb_step(&g, A, Bc);
+        if (r) { fprintf(stderr, "  boolean walk: verdict %d after %d iterations\n", r, g.it); break; }
+    }
+    fprintf(stderr, "  gjk_collides(tc) = %d, cores_collide = %d\n", gjk_collides(A, Bc, tc), cores_collide(A, Bc, thr));
+    free(wc); free(frames); free(rc);
+    return 0;
 }
 
 void orc_stats(long long *out, int reset) {

@@ -200,3 +200,76 @@ def test_hull_of_a_box_equals_the_box_primitive():
             assert abs(dh - db) < 1e-9, (tb, dh, db)
         else:
             assert dh < 0 and dh <= db + 1e-9, (tb, dh, db)
+
+
+def _sheared(T, eps):
+    """The pose a link gets when its joint axis is given to a few digits only: Rodrigues with a non-unit axis leaves the
+    rotation orthonormal to ~eps (the reference uses the axis as given, robots/helpers.py:43-55)."""
+    S = T.copy()
+    S[:3, 2] *= 1.0 + eps
+    return S
+
+
+def test_cylinder_support_with_an_axis_that_is_not_quite_unit():
+    """Captured from the fuzz campaign (seed 70503, row 41921): a cylinder on a link whose rotation is orthonormal to 2.4e-6
+    only, 7.2 mm from a flat hull.  The boolean walk reached a search direction parallel to the cylinder axis to 1e-9; the
+    old support routine then returned a point 25 mm beyond the cap and both GJK predicates reported a collision."""
+    Ta = np.eye(4)
+    Ta[:3] = [[-0.3517763815178784, -0.5800229888189756, -0.7347301184496722, 0.4215516531568988],
+              [-0.2353265310503352, -0.7048913061458668, 0.6691408572229722, 0.765730064901918],
+              [-0.9060293326209685, 0.40829119121473895, 0.111465674169479, 0.21667821304131982]]
+    Tb = np.eye(4)
+    Tb[:3] = [[0.5764151840484136, -0.8030006847075268, -0.15144449794454842, 0.5383620147343717],
+              [0.6486553841895438, 0.5623445676167756, -0.5128496659195719, 0.592557737901488],
+              [0.49698262360000955, 0.19737904557258373, 0.8450146650848772, 0.13278055792270793]]
+    V = np.array([[-0.13120378261111507, -0.020409024073481954, 0.010804724290791042], [-0.0997475749780061, -0.06307594605645662, -0.004016755366807444],
+                  [-0.07617097416858774, -0.03600921341436852, -0.017783099370204822], [-0.07058986061864665, 0.05285513033391884, -0.016917463431851895],
+                  [-0.048740045190185974, -0.0862752884480052, 0.011847596983291896], [-0.04576513014462036, 0.04475304731113082, 0.020094230150352152],
+                  [-0.02409959318614671, 0.03631267947495086, 0.020791416960678908], [-0.015527361410270682, -0.03444917188470428, -0.022012430250863347],
+                  [-0.01397888116297892, 0.012336178246702356, 0.022173955965907648], [0.002025428536813499, -0.04194707187471403, -0.020320262228817408],
+                  [0.01046466592576778, 0.06851273887540982, 0.0011497061531134693], [0.016992773884378382, 0.03058686127917226, -0.018051213524855732],
+                  [0.02701514434902899, -0.10461295799492545, 0.003752622236137681], [0.07184753131671641, 0.08195956001253224, 0.006286442592893948],
+                  [0.08279216210149143, -0.04719529790758362, 0.01876537070002667], [0.08566116288233198, 0.08699239942202616, 0.0027088916083875436],
+                  [0.11379277563853701, -0.02608700210476586, -0.012887066137633192], [0.11523155883549291, 0.04575237880316217, -0.006386667330547111]])
+    assert abs(np.linalg.norm(Ta[:3, 2]) ** 2 - 1.0) > 1e-6          # the axis of the captured pose is not unit
+    hs = HullSet()
+    ih = hs.add(convex_hull(V))
+    cyl = [0.0299, 0.1126, 0.0, 0.0]
+    d = shape_distance_h(hs, 3, Ta, cyl, 5, Tb, [ih, 0, 0, 0])[0]
+    assert 0.0070 < d < 0.0075
+    for thr in (0.0, 1e-6, 0.007):
+        assert not shape_collides_h(hs, 3, Ta, cyl, 5, Tb, [ih, 0, 0, 0], thr)
+        assert not shape_collides_h(hs, 5, Tb, [ih, 0, 0, 0], 3, Ta, cyl, thr)
+    assert shape_collides_h(hs, 3, Ta, cyl, 5, Tb, [ih, 0, 0, 0], 0.0075)
+
+
+def test_predicates_agree_with_the_distance_under_sheared_poses():
+    """Cylinders against every solid under poses orthonormal to 1e-5 / 1e-3 only, with the partner placed on the cylinder's
+    axis (the walk's first direction is then axial): the boolean walk (threshold 0), the distance predicate (1e-6) and the
+    distance routine have to tell the same story."""
+    rng = np.random.default_rng(91)
+    hs = HullSet()
+    _random_hull(rng, hs)
+    n_close = 0
+    for it in range(1500):
+        eps = float(rng.choice([0.0, 2.4e-6, 1e-5, 1e-3]))
+        Ta = _sheared(random_pose(rng, 0.2), eps)
+        rad, hh = rng.uniform(0.02, 0.1), rng.uniform(0.05, 0.3)
+        tb = int(rng.choice([2, 3, 5]))
+        Tb = _sheared(random_pose(rng, 0.2), eps)
+        if it % 2 == 0:       # partner centred on the cylinder's axis, beyond a cap
+            Tb[:3, 3] = Ta[:3, 3] + Ta[:3, 2] * (hh + rng.uniform(0.0, 0.25)) * rng.choice([-1.0, 1.0])
+        if tb == 5:
+            ib, _ = _random_hull(rng, hs)
+            pb = [ib, 0.0, 0.0, 0.0]
+        else:
+            pb = random_param(rng, tb)
+        pa = [rad, hh, 0.0, 0.0]
+        d = shape_distance_h(hs, 3, Ta, pa, tb, Tb, pb)[0]
+        if abs(d) < 1e-5:
+            continue
+        n_close += abs(d) < 0.02
+        for thr in (0.0, 1e-6):
+            assert shape_collides_h(hs, 3, Ta, pa, tb, Tb, pb, thr) == (d < thr), (it, eps, tb, d, thr)
+            assert shape_collides_h(hs, tb, Tb, pb, 3, Ta, pa, thr) == (d < thr), (it, eps, tb, d, thr)
+    assert n_close > 50
