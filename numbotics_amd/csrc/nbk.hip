@@ -1211,6 +1211,7 @@ NBK_DEV double readlane_f64(double v, int l) {
 // saturates at ~90 appends/us (MI355X_MICROARCH.md, row "dequeue"), which 15k waves would all hit.
 constexpr int NSUB = 256;
 constexpr int CNT_STRIDE = 16;          // one 128-byte line per counter
+constexpr int CNT_TICKET = 1;           // word 1 of a counter's line: the next chunk of that sub-queue the narrowphase hands out
 
 // Items are routed by the kind class of their pair (vp_cls: box-box, box-cylinder, cylinder-cylinder, the rest):
 // class c owns cls_groups[c] of the NSUB sub-queues (in proportion to its pairs), a block appends to the (block % groups)-th.  The chunks k_narrow takes are then kind-homogeneous -- one core layout, one
@@ -1250,6 +1251,7 @@ NBK_DEV void flush_items(const DevModel& m, unsigned* lds_queue, int qn, int64_t
 // when the call was replayed from a captured hipGraph (ROCm 7.2), a plain kernel node does
 __global__ void k_zero_counters(unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ flags, int flag_words) {
     q_count[threadIdx.x * CNT_STRIDE] = 0ull;
+    q_count[threadIdx.x * CNT_STRIDE + CNT_TICKET] = 0ull;
     for (int i = threadIdx.x; i < flag_words; i += NSUB) flags[i] = 0ull;
 }
 
@@ -1287,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
                                                      unsigned long long* __restrict__ flags, int flag_words) {
     const int t = threadIdx.x;
     const int W = m.n_wshapes;
-    for (int s = 0; s < n_sets; ++s) q_count[((size_t)s * NSUB + t) * CNT_STRIDE] = 0ull;
+    for (int s = 0; s < n_sets; ++s) { q_count[((size_t)s * NSUB + t) * CNT_STRIDE] = 0ull; q_count[((size_t)s * NSUB + t) * CNT_STRIDE + CNT_TICKET] = 0ull; }
     for (int i = t; i < flag_words; i += 256) flags[i] = 0ull;           // overflow marks of the tile's blocks
     const FTab v = ftab_view(tab, W);
     float* rkey = const_cast<float*>(v.rkey); float* rcert = const_cast<float*>(v.rcert);
@@ -2277,14 +2279,20 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
 
 // core of shape `ref` (robot: from the replayed frame T; world: table).  Everything here is per lane.
 NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
-    if (ref >= 0) {
+    // the constants of either table are read through one pointer and stored once, outside the branch: with the stores inside,
+    // the compiler sank "the last store of either branch" into one store at a lane-varying address (o.rho on one side, o.c[0]
+    // on the other), which pinned those members of both cores in scratch -- and every later read of them
+    const bool robot = ref >= 0;
+    const int w = robot ? 0 : ~ref;
+    const double* wc = m.ws_core + 18 * w;
+    const double* cc = robot ? m.rs_core + 6 * ref : wc + 12;
+    o.kind = robot ? m.rs_kind[ref] : m.ws_kind[w];
+    o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4]; o.rho = cc[5];
+    if (robot) {
         const double* loc = m.rs_local + 12 * ref;
-        const double* cc = m.rs_core + 6 * ref;
         double Rl[9], tl[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { Rl[3 * i] = loc[4 * i]; Rl[3 * i + 1] = loc[4 * i + 1]; Rl[3 * i + 2] = loc[4 * i + 2]; tl[i] = loc[4 * i + 3]; }
-        o.kind = m.rs_kind[ref];
-        o.h[0] = cc[0]; o.h[1] = cc[1]; o.h[2] = cc[2]; o.rad = cc[3]; o.margin = cc[4]; o.rho = cc[5];
         xf_mul_pos(T, tl, o.c);
         if (o.kind == K_SEG || o.kind == K_CYL) {
             xf_mul_col(T, Rl, 2, o.ax[2]);
@@ -2293,7 +2301,9 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
             for (int j = 0; j < 3; ++j) xf_mul_col(T, Rl, j, o.ax[j]);
         }
     } else {
-        load_wcore(m, ~ref, o);
+        o.c[0] = wc[0]; o.c[1] = wc[1]; o.c[2] = wc[2];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { o.ax[j][0] = wc[3 + 3 * j]; o.ax[j][1] = wc[4 + 3 * j]; o.ax[j][2] = wc[5 + 3 * j]; }
     }
 }
 
@@ -2305,6 +2315,9 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
 //            lanes new items existed while chunks were larger than the wave; with 64-item chunks it never had
 //            anything left to hand out and only cost 18 KB of LDS per workgroup.
 constexpr int NARROW_T = 64;
+#ifndef NARROW_WAVES_GEN
+#define NARROW_WAVES_GEN 2
+#endif
 constexpr int NARROW_WAVES_BOOL = 2;     // waves per SIMD the boolean-only narrowphase is compiled for (3 needs ~120 spilled
                                          // registers: measured slower)
 
@@ -2320,12 +2333,13 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
 __device__ unsigned long long g_narrow_prof[16];
 #define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
 
-// MODE 0: both walks (tc == 0 picks the boolean one per item), 1: boolean walk only, 2: distance predicate only (the host has
-// established tc != 0 for every pair that can reach GJK), 3: distance predicate with tc > 0 everywhere (a positive threshold
-// such as IRIS' 1e-6: no overlap-depth estimate is ever needed)
+// MODE 0: any mix of tc (per item: tc >= 0 walks the boolean GJK, inflated by tc when tc > 0, tc < 0 runs the distance
+// predicate), 1: tc == 0 for every pair that can reach GJK -- boolean walk only, 2: tc < 0 everywhere -- distance predicate
+// only, 3: tc > 0 everywhere (a positive threshold such as IRIS' 1e-6, or a margin on every solid) -- inflated walk, then the
+// distance predicate for what it leaves undecided
 template <int MODE>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
-                         const unsigned long long* __restrict__ q_items, const unsigned long long* __restrict__ q_count,
+                         const unsigned long long* __restrict__ q_items, unsigned long long* q_count,
                          unsigned long long cap, uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                          double* qstage, unsigned long long* __restrict__ count_next) {
     // block (sub, part): every nparts-th 128-item chunk of sub-queue `sub`
@@ -2333,7 +2347,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     const unsigned part = blockIdx.x / NSUB;
     const unsigned nparts = gridDim.x / NSUB;
     // the other counter set is idle during this call: clear it for the next one
-    if (count_next != nullptr && part == 0 && threadIdx.x == 0) count_next[(size_t)sub * CNT_STRIDE] = 0ull;
+    if (count_next != nullptr && part == 0 && threadIdx.x == 0) { count_next[(size_t)sub * CNT_STRIDE] = 0ull; count_next[(size_t)sub * CNT_STRIDE + CNT_TICKET] = 0ull; }
     // agent-scope loads: the queue was written by another kernel (possibly replayed from a hipGraph).
     // The kernel is latency-bound, so dependent global round trips are kept to three: {count, first item} ->
     // {pair record, q row} -> shape constants.  The first chunk's item is loaded before the count is known (the slot
@@ -2348,7 +2362,15 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     unsigned long long n = __hip_atomic_load(q_count + sub * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (n > cap) n = cap;
     if (NBK_DBG(m) & 1) n = 0;
-    for (unsigned long long i0 = (unsigned long long)part * NARROW_T; i0 < n; i0 += (unsigned long long)nparts * NARROW_T) {
+    // chunks: workgroup `part` starts with chunk `part`; further chunks are handed out by a ticket per sub-queue, so that a
+    // workgroup held up by a slow item (a GJK walk of 30+ steps where 5 are usual) takes fewer chunks instead of finishing its fixed
+    // share late -- the kernel ends with its slowest workgroup.  The next ticket is drawn before the current chunk is worked on.
+    unsigned long long* ticket = q_count + sub * CNT_STRIDE + CNT_TICKET;
+    for (unsigned long long chunk = part; chunk * NARROW_T < n; ) {
+        const unsigned long long i0 = chunk * NARROW_T;
+        unsigned next_ticket = 0u;
+        if (threadIdx.x == 0) next_ticket = (unsigned)atomicAdd(ticket, 1ull);
+        chunk = nparts;          // + the ticket, added at the end of the body
         // ---- phase 1 -----------------------------------------------------------------------------------------------
         {
             const unsigned long long i = i0 + threadIdx.x;
@@ -2450,23 +2472,36 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
-#ifdef NBK_PROTO_INFL
             } else if constexpr (MODE == 3) {
+                // tc > 0 everywhere: the boolean walk on the inflated core, then the distance iteration for what it leaves
+                // undecided.  The kernel's time is set by its slowest items: with a cap of 20 steps some 10-2000 items per 1e6
+                // configurations fell through to the distance iteration (~9 steps of 4.4 us each: 87 us, no better than running it
+                // on everything); with 64 none does on the benchmark scene and the tail is the walk's own 38 steps (66 us).
                 GjkBool gb;
                 gjkb_init(gb, A, Bc);
+                bool hard = false;
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
-                        const int r = gjkb_step<true>(gb, A, Bc, tc);
-                        if (r != 0) { if (r >= 2) mark_hit(b, mask_bits, mask_bytes); if (r == 3) atomicAdd(&g_narrow_prof[11], 1ull); have = false; }
+                        const int r = gjkb_step<1>(gb, A, Bc, tc);
+                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); hard = r == 3; have = false; }
                     }
                 }
-#endif
-            } else if constexpr (MODE == 2 || MODE == 3) {
+                if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
+                    GjkPred g;
+                    gjk_pred_init(g, A, Bc);
+                    while (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
+                        if (hard) {
+                            const int r = gjk_pred_step<true>(g, A, Bc, tc);
+                            if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); hard = false; }
+                        }
+                    }
+                }
+            } else if constexpr (MODE == 2) {
                 GjkPred g;
                 gjk_pred_init(g, A, Bc);
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
-                        const int r = gjk_pred_step<MODE == 3>(g, A, Bc, tc);
+                        const int r = gjk_pred_step(g, A, Bc, tc);
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
@@ -2475,15 +2510,18 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 GjkPred g;
                 gjkb_init(gb, A, Bc);
                 gjk_pred_init(g, A, Bc);
+                bool walk = tc >= 0.0;                   // (a NaN threshold takes the distance iteration, as before)
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
-                        const int r = (tc == 0.0) ? gjkb_step(gb, A, Bc) : gjk_pred_step(g, A, Bc, tc);
-                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
+                        const int r = walk ? gjkb_step<2>(gb, A, Bc, tc) : gjk_pred_step(g, A, Bc, tc);
+                        if (r == 3) walk = false;        // the inflated walk gave up: the distance iteration starts from its own (untouched) state
+                        else if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); have = false; }
                     }
                 }
             }
         }
         __syncthreads();
+        chunk += (unsigned)__builtin_amdgcn_readfirstlane((int)next_ticket);
         if (prof && i0 == (unsigned long long)part * NARROW_T) {
             NBK_STAMP(6);
             if (threadIdx.x == 0) {
@@ -2499,25 +2537,25 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
 
 __global__ __launch_bounds__(NARROW_T, NARROW_WAVES_BOOL) void k_narrow_bool(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                       const unsigned long long* __restrict__ q_items,
-                                                      const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                      unsigned long long* q_count, unsigned long long cap,
                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
     unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
     narrow_body<1>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage, count_next);
 }
 
-__global__ __launch_bounds__(NARROW_T, 2) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+__global__ __launch_bounds__(NARROW_T, NARROW_WAVES_GEN) void k_narrow(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                  const unsigned long long* __restrict__ q_items,
-                                                 const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                 unsigned long long* q_count, unsigned long long cap,
                                                  uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
     unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
     narrow_body<0>(m, es, q, thr, q_items, q_count, cap, mask_bits, mask_bytes, qstage, count_next);
 }
 
-__global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pred(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
+__global__ __launch_bounds__(NARROW_T, NARROW_WAVES_GEN) void k_narrow_pred(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                       const unsigned long long* __restrict__ q_items,
-                                                      const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                      unsigned long long* q_count, unsigned long long cap,
                                                       uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
     unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
@@ -2526,7 +2564,7 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pred(DevModel m, EdgeSrc
 
 __global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pos(DevModel m, EdgeSrc es, const double* __restrict__ q, double thr,
                                                      const unsigned long long* __restrict__ q_items,
-                                                     const unsigned long long* __restrict__ q_count, unsigned long long cap,
+                                                     unsigned long long* q_count, unsigned long long cap,
                                                      uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
     unsigned long long* __restrict__ count_next) {
     extern __shared__ double qstage[];          // NARROW_T * n_q doubles
@@ -3872,13 +3910,14 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         NBK_HIP(hipEventRecord(iw0->ev_fork, st0));                          // the odd tiles' inputs are whatever the caller's stream has produced
         NBK_HIP(hipStreamWaitEvent(iw0->aux_stream, iw0->ev_fork, 0));
     }
-    // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, none zero ->
-    // distance predicate only, else the build with both
-    bool any_zero = false, any_nonzero = false, any_negative = false;
+    // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, all positive -> the
+    // inflated walk (+ fallback), all negative -> distance predicate only, else the build with both
+    bool any_zero = false, any_positive = false, any_negative = false;
     for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
         const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
-        if (tc == 0.0) any_zero = true; else any_nonzero = true;
-        if (!(tc > 0.0)) any_negative = true;          // (a NaN threshold counts as not positive)
+        if (tc == 0.0) any_zero = true;
+        else if (tc > 0.0) any_positive = true;
+        else any_negative = true;                      // (a NaN threshold counts as negative: the distance predicate)
     }
     const int S = m->d.n_rshapes;
     const bool use_reg = S <= 16 && (!g_opt.no_reg_broad || !m->lds_broad_ok);
@@ -3947,11 +3986,11 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         unsigned parts = 4u * nblk / NSUB;
         { const unsigned pmax = g_opt.narrow_parts_max > 0 ? (unsigned)g_opt.narrow_parts_max : 16u; parts = parts < 4u ? 4u : parts; parts = parts > pmax ? pmax : parts; }
         if (nblk <= 4u) parts = 1u;                      // a handful of configurations (the scalar calls): 256 workgroups are plenty
-        if (!any_nonzero)
+        if (!any_positive && !any_negative)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero && !any_negative)
             hipLaunchKernelGGL(k_narrow_pos, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
-        else if (!any_zero)
+        else if (!any_zero && !any_positive)
             hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else
             hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);

@@ -110,14 +110,17 @@ struct Core {
     int kind;            // wave-uniform
     double c[3];
     double ax[3][3];     // ax[j] = world direction of local axis j (box, hull: all three; seg/cyl: ax[2])
-    union {
-        double h[3];     // uniform: seg/cyl h[0] = half length; box half extents
-        HullRef hull;    // K_HULL: the same 24 bytes of the shape tables hold the hull's device pointers and counts
-    };
+    double h[3];         // uniform: seg/cyl h[0] = half length; box half extents; K_HULL: the 24 bytes of a HullRef (the shape
+                         // tables hold the hull's device pointers and counts there), read through hull_* below.  Not a union:
+                         // with one the compiler kept h[] of both cores in scratch, and every box support read it from there
     double rad;          // uniform: cylinder radius
     double margin;       // uniform
     double rho;          // uniform: bounding radius of the core about c
 };
+NBK_DEV const double* hull_hv(const Core& s) { return reinterpret_cast<const double*>(__builtin_bit_cast(unsigned long long, s.h[0])); }
+NBK_DEV const double* hull_hp(const Core& s) { return reinterpret_cast<const double*>(__builtin_bit_cast(unsigned long long, s.h[1])); }
+NBK_DEV int hull_hn(const Core& s) { return (int)(unsigned)(__builtin_bit_cast(unsigned long long, s.h[2]) & 0xFFFFFFFFull); }
+NBK_DEV int hull_hf(const Core& s) { return (int)(unsigned)(__builtin_bit_cast(unsigned long long, s.h[2]) >> 32); }
 
 NBK_DEV void core_support(const Core& s, const double* d, double* o) {
     switch (s.kind) {
@@ -149,8 +152,8 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
         case K_HULL: {
             // direction in local coordinates, first maximum over the vertex list, that vertex back to the world
             const double dl0 = dot3(d, s.ax[0]), dl1 = dot3(d, s.ax[1]), dl2 = dot3(d, s.ax[2]);
-            const double* hv = s.hull.hv;
-            const int hn = s.hull.hn;
+            const double* hv = hull_hv(s);
+            const int hn = hull_hn(s);
             double best = -NBK_INF;
             int bi = 0;
             // four vertices per trip: their twelve loads are issued together (per-lane loads in k_narrow, where the lanes of a wave
@@ -209,8 +212,8 @@ NBK_DEV double core_halfwidth(const Core& s, const double* n) {
 NBK_DEV void core_extents(const Core& s, const double* n, double& neg, double& pos) {
     if (s.kind != K_HULL) { const double hw = core_halfwidth(s, n); neg = hw; pos = hw; return; }
     const double dl0 = dot3(n, s.ax[0]), dl1 = dot3(n, s.ax[1]), dl2 = dot3(n, s.ax[2]);
-    const double* hv = s.hull.hv;
-    const int hn = s.hull.hn;
+    const double* hv = hull_hv(s);
+    const int hn = hull_hn(s);
     double hi = -NBK_INF, lo = NBK_INF;
     for (int k = 0; k < hn; ++k) {
         const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
@@ -227,14 +230,29 @@ constexpr int GJK_MAXIT = 64;
 constexpr double GJK_EPS_REL = 1e-10;
 constexpr double GJK_TINY2 = 1e-30;
 
+// Every slot is its own member, picked with SX_Y / SX_A / SX_B / SX_LAM on a COMPILE-TIME slot number: with y[4][3] the
+// compiler folded the select chains below into loads and stores at a lane-varying scratch address (96-168 B of private memory
+// per lane, several dependent scratch round trips per iteration).
 template <bool WIT>
 struct Simplex {
-    double y[4][3];
-    double a[WIT ? 4 : 1][3];
-    double b[WIT ? 4 : 1][3];
-    double lam[4];
+    double y0[3], y1[3], y2[3], y3[3];
+    double a0[WIT ? 3 : 1], a1[WIT ? 3 : 1], a2[WIT ? 3 : 1], a3[WIT ? 3 : 1];
+    double b0[WIT ? 3 : 1], b1[WIT ? 3 : 1], b2[WIT ? 3 : 1], b3[WIT ? 3 : 1];
+    double lam0, lam1, lam2, lam3;
     int n;
 };
+#define SX_Y(s, i) ((i) == 0 ? (s).y0 : ((i) == 1 ? (s).y1 : ((i) == 2 ? (s).y2 : (s).y3)))
+#define SX_A(s, i) ((i) == 0 ? (s).a0 : ((i) == 1 ? (s).a1 : ((i) == 2 ? (s).a2 : (s).a3)))
+#define SX_B(s, i) ((i) == 0 ? (s).b0 : ((i) == 1 ? (s).b1 : ((i) == 2 ? (s).b2 : (s).b3)))
+#define SX_LAM(s, i) ((i) == 0 ? (s).lam0 : ((i) == 1 ? (s).lam1 : ((i) == 2 ? (s).lam2 : (s).lam3)))
+
+// one of four VALUES by a lane-varying slot number.  The empty asm makes the operands opaque registers: without it the compiler
+// folds "select of loads from consecutive members" into one load at a lane-varying address, which keeps the whole simplex in
+// scratch
+NBK_DEV double sx_pick(int k, double v0, double v1, double v2, double v3) {
+    asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+    return k == 0 ? v0 : (k == 1 ? v1 : (k == 2 ? v2 : v3));
+}
 
 // result of a closest-point query on a sub-simplex: up to 3 kept slots (indices into the CURRENT simplex)
 struct Closest { double v[3]; int idx[3]; double lam[3]; int n; };
@@ -243,7 +261,7 @@ template <bool WIT>
 NBK_DEV void sx_get(const Simplex<WIT>& s, int i, double* y) {
     // select chain (i is lane-varying)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) y[c] = i == 0 ? s.y[0][c] : (i == 1 ? s.y[1][c] : (i == 2 ? s.y[2][c] : s.y[3][c]));
+    for (int c = 0; c < 3; ++c) y[c] = sx_pick(i, s.y0[c], s.y1[c], s.y2[c], s.y3[c]);
 }
 
 NBK_DEV void closest_seg(const double* A, const double* Bp, int i0, int i1, Closest& r) {
@@ -317,10 +335,10 @@ NBK_DEV void sx_keep(Simplex<WIT>& s, const Closest& r) {
         const int k = r.idx[i];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            ny[i][c] = k == 0 ? s.y[0][c] : (k == 1 ? s.y[1][c] : (k == 2 ? s.y[2][c] : s.y[3][c]));
+            ny[i][c] = sx_pick(k, s.y0[c], s.y1[c], s.y2[c], s.y3[c]);
             if constexpr (WIT) {
-                na[i][c] = k == 0 ? s.a[0][c] : (k == 1 ? s.a[1][c] : (k == 2 ? s.a[2][c] : s.a[3][c]));
-                nb[i][c] = k == 0 ? s.b[0][c] : (k == 1 ? s.b[1][c] : (k == 2 ? s.b[2][c] : s.b[3][c]));
+                na[i][c] = sx_pick(k, s.a0[c], s.a1[c], s.a2[c], s.a3[c]);
+                nb[i][c] = sx_pick(k, s.b0[c], s.b1[c], s.b2[c], s.b3[c]);
             }
         }
     }
@@ -329,10 +347,10 @@ NBK_DEV void sx_keep(Simplex<WIT>& s, const Closest& r) {
         if (i < r.n) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                s.y[i][c] = ny[i][c];
-                if constexpr (WIT) { s.a[i][c] = na[i][c]; s.b[i][c] = nb[i][c]; }
+                SX_Y(s, i)[c] = ny[i][c];
+                if constexpr (WIT) { SX_A(s, i)[c] = na[i][c]; SX_B(s, i)[c] = nb[i][c]; }
             }
-            s.lam[i] = r.lam[i];
+            SX_LAM(s, i) = r.lam[i];
         }
     }
     s.n = r.n;
@@ -345,14 +363,14 @@ NBK_DEV void sx_keep(Simplex<WIT>& s, const Closest& r) {
 template <bool WIT>
 NBK_DEV int gjk_advance(Simplex<WIT>& sx, const double* w, const double* sa, const double* sb, double* v, double& vv_prev) {
     const int k = sx.n;
+    // (value selects into every slot, not a store under `if (i == k)`: that one becomes a store at a lane-varying address)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (i == k) {
+        const bool here = i == k;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                sx.y[i][c] = w[c];
-                if constexpr (WIT) { sx.a[i][c] = sa[c]; sx.b[i][c] = sb[c]; }
-            }
+        for (int c = 0; c < 3; ++c) {
+            SX_Y(sx, i)[c] = here ? w[c] : SX_Y(sx, i)[c];
+            if constexpr (WIT) { SX_A(sx, i)[c] = here ? sa[c] : SX_A(sx, i)[c]; SX_B(sx, i)[c] = here ? sb[c] : SX_B(sx, i)[c]; }
         }
     }
     Closest r;
@@ -360,37 +378,37 @@ NBK_DEV int gjk_advance(Simplex<WIT>& sx, const double* w, const double* sa, con
     r.v[0] = r.v[1] = r.v[2] = 0.0;
     bool inside = false;
     if (k == 0) {
-        copy3(sx.y[0], r.v); r.idx[0] = 0; r.lam[0] = 1.0; r.n = 1;
+        copy3(sx.y0, r.v); r.idx[0] = 0; r.lam[0] = 1.0; r.n = 1;
     } else if (k == 1) {
-        closest_seg(sx.y[0], sx.y[1], 0, 1, r);
+        closest_seg(sx.y0, sx.y1, 0, 1, r);
     } else if (k == 2) {
-        closest_tri(sx.y[0], sx.y[1], sx.y[2], 0, 1, 2, r);
+        closest_tri(sx.y0, sx.y1, sx.y2, 0, 1, 2, r);
     } else {
         // faces (0,1,2|3) (0,2,3|1) (0,3,1|2) (1,3,2|0): best of the faces the origin is outside of
         double best = NBK_INF;
         bool any = false;
         Closest cr;
-        if (outside_face(sx.y[0], sx.y[1], sx.y[2], sx.y[3])) {
+        if (outside_face(sx.y0, sx.y1, sx.y2, sx.y3)) {
             any = true;
-            closest_tri(sx.y[0], sx.y[1], sx.y[2], 0, 1, 2, cr);
+            closest_tri(sx.y0, sx.y1, sx.y2, 0, 1, 2, cr);
             const double dd = dot3(cr.v, cr.v);
             if (dd < best) { best = dd; r = cr; }
         }
-        if (outside_face(sx.y[0], sx.y[2], sx.y[3], sx.y[1])) {
+        if (outside_face(sx.y0, sx.y2, sx.y3, sx.y1)) {
             any = true;
-            closest_tri(sx.y[0], sx.y[2], sx.y[3], 0, 2, 3, cr);
+            closest_tri(sx.y0, sx.y2, sx.y3, 0, 2, 3, cr);
             const double dd = dot3(cr.v, cr.v);
             if (dd < best) { best = dd; r = cr; }
         }
-        if (outside_face(sx.y[0], sx.y[3], sx.y[1], sx.y[2])) {
+        if (outside_face(sx.y0, sx.y3, sx.y1, sx.y2)) {
             any = true;
-            closest_tri(sx.y[0], sx.y[3], sx.y[1], 0, 3, 1, cr);
+            closest_tri(sx.y0, sx.y3, sx.y1, 0, 3, 1, cr);
             const double dd = dot3(cr.v, cr.v);
             if (dd < best) { best = dd; r = cr; }
         }
-        if (outside_face(sx.y[1], sx.y[3], sx.y[2], sx.y[0])) {
+        if (outside_face(sx.y1, sx.y3, sx.y2, sx.y0)) {
             any = true;
-            closest_tri(sx.y[1], sx.y[3], sx.y[2], 1, 3, 2, cr);
+            closest_tri(sx.y1, sx.y3, sx.y2, 1, 3, 2, cr);
             const double dd = dot3(cr.v, cr.v);
             if (dd < best) { best = dd; r = cr; }
         }
@@ -411,15 +429,15 @@ NBK_DEV void sx_init(Simplex<WIT>& sx) {
     sx.n = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        sx.lam[i] = 0.0;
+        SX_LAM(sx, i) = 0.0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) sx.y[i][c] = 0.0;
+        for (int c = 0; c < 3; ++c) SX_Y(sx, i)[c] = 0.0;
     }
     if constexpr (WIT) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { sx.a[i][c] = 0.0; sx.b[i][c] = 0.0; }
+            for (int c = 0; c < 3; ++c) { SX_A(sx, i)[c] = 0.0; SX_B(sx, i)[c] = 0.0; }
     }
 }
 
@@ -428,7 +446,7 @@ NBK_DEV bool sx_has(const Simplex<WIT>& sx, const double* w) {
     bool dup = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (i < sx.n && sx.y[i][0] == w[0] && sx.y[i][1] == w[1] && sx.y[i][2] == w[2]) dup = true;
+        if (i < sx.n && SX_Y(sx, i)[0] == w[0] && SX_Y(sx, i)[1] == w[1] && SX_Y(sx, i)[2] == w[2]) dup = true;
     return dup;
 }
 
@@ -470,13 +488,17 @@ NBK_DEV bool gjk_cores(const Core& A, const Core& Bc, double* vout, double* pa, 
         pa[0] = pa[1] = pa[2] = 0.0; pb[0] = pb[1] = pb[2] = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i < sx.n) { axpy3(sx.lam[i], sx.a[i], pa, pa); axpy3(sx.lam[i], sx.b[i], pb, pb); }
+            if (i < sx.n) { axpy3(SX_LAM(sx, i), SX_A(sx, i), pa, pa); axpy3(SX_LAM(sx, i), SX_B(sx, i), pb, pb); }
         }
     }
     return false;
 }
 
 NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
+// the predicate's use of it (negative tc, penetrating cores) goes through a real call on COPIES of the cores: inlined into the
+// GJK loop its fifteen-axis family drove k_narrow / k_narrow_pred to 600+ spilled VGPRs once the cores lived in registers
+__device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc);
+NBK_DEV double overlap_depth_call(const Core& A, const Core& Bc) { return overlap_depth_copy(A, Bc); }
 
 // GJK predicate: dist(coreA, coreB) < tc ?  Same iteration, but it returns as soon as the support-plane
 // lower bound reaches tc (free) or the simplex point drops below tc (colliding).
@@ -532,7 +554,7 @@ NBK_DEV int gjk_pred_step(GjkPred& g, const Core& A, const Core& Bc, double tc) 
                     if (POSITIVE || tc >= 0.0) return 2;
                     if constexpr (!POSITIVE) {
                         double nrm[3];
-                        return (-overlap_depth(A, Bc, nrm) < tc) ? 2 : 1;
+                        return (-overlap_depth_call(A, Bc) < tc) ? 2 : 1;
                     }
                 }
             } else if (st == 2) finish = true;
@@ -559,9 +581,7 @@ NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
 
 // ---- boolean GJK (the predicate for tc == 0): mirrors gjk_intersect of the oracle ------------------------------
 constexpr int GJKB_MAXIT = 32;
-#ifndef GJKB_INFL_MAXIT
-#define GJKB_INFL_MAXIT 12
-#endif
+constexpr int GJKB_INFL_MAXIT = 64;     // the inflated walk (tc > 0): then the distance iteration decides (figures: see the oracle)
 struct GjkBool { double p[3][3]; int n; double d[3]; int it; };   // p[0] oldest; at most 3 points are kept between steps
 
 NBK_DEV void mink_support(const Core& A, const Core& Bc, const double* d, double* w) {
@@ -617,13 +637,18 @@ NBK_DEV void gjkb_init(GjkBool& g, const Core& A, const Core& Bc) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) { g.p[i][0] = 0.0; g.p[i][1] = 0.0; g.p[i][2] = 0.0; }
 }
-// one iteration: 0 = continue, 1 = free, 2 = intersecting
-template <bool INFL = false>
+// one iteration: 0 = continue, 1 = free, 2 = intersecting, 3 = undecided (inflated walk only).
+// INFL 0: the cores as they are (tc == 0).  INFL 1: core A inflated by a ball of radius tc > 0 -- its support point moves by
+// tc d/|d| -- so that "A (+) ball(tc) meets B" decides dist(A, B) < tc with the cheap walk instead of the distance iteration;
+// the rounded shape can take long to separate from a near-tangent partner, so the walk gives up after GJKB_INFL_MAXIT steps
+// (or with the origin on the simplex) and the caller falls back to gjk_collides.  INFL 2: per item, inflated iff tc > 0.
+template <int INFL = 0>
 NBK_DEV int gjkb_step(GjkBool& g, const Core& A, const Core& Bc, double tc = 0.0) {
-    if (g.it >= (INFL ? GJKB_INFL_MAXIT : GJKB_MAXIT)) return INFL ? 3 : 2;
+    const bool infl = INFL == 1 || (INFL == 2 && tc > 0.0);
+    if (g.it >= (infl ? GJKB_INFL_MAXIT : GJKB_MAXIT)) return infl ? 3 : 2;
     double a[3];
     mink_support(A, Bc, g.d, a);
-    if constexpr (INFL) {
+    if (infl) {
         const double k = tc / nbk_sqrt(dot3(g.d, g.d));
         axpy3(k, g.d, a, a);
     }
@@ -666,13 +691,19 @@ NBK_DEV int gjkb_step(GjkBool& g, const Core& A, const Core& Bc, double tc = 0.0
         if (enclosed) return 2;
         gjkb_triangle(g, x, y, a);
     }
-    if (dot3(g.d, g.d) == 0.0) return 2;
+    if (dot3(g.d, g.d) == 0.0) return infl ? 3 : 2;
     return 0;
 }
 NBK_DEV bool gjk_intersect(const Core& A, const Core& Bc) {
     GjkBool g;
     gjkb_init(g, A, Bc);
     while (true) { const int r = gjkb_step(g, A, Bc); if (r != 0) return r == 2; }
+}
+// dist(A, B) < tc for tc > 0 by the inflated walk: 1 colliding, 0 free, -1 undecided
+NBK_DEV int gjk_intersect_inflated(const Core& A, const Core& Bc, double tc) {
+    GjkBool g;
+    gjkb_init(g, A, Bc);
+    while (true) { const int r = gjkb_step<1>(g, A, Bc, tc); if (r != 0) return r == 3 ? -1 : (r == 2 ? 1 : 0); }
 }
 
 // ---- overlap depth over the candidate axis family ---------------------------------------------
@@ -706,7 +737,7 @@ NBK_DEV void try_axis(const Core& A, const Core& Bc, const double* delta, const 
 
 // world direction of face f of a hull core
 NBK_DEV void hull_face_normal(const Core& s, int f, double* n) {
-    const double* pl = s.hull.hp + 4 * f;
+    const double* pl = hull_hp(s) + 4 * f;
     const double p0 = pl[0], p1 = pl[1], p2 = pl[2];
     n[0] = 0.0; n[1] = 0.0; n[2] = 0.0;
     axpy3(p0, s.ax[0], n, n);
@@ -738,13 +769,18 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
                 try_axis(A, Bc, delta, cr, best, normal);
             }
     // face normals of hull cores (exact for a point inside a hull, an upper bound otherwise: no edge-edge axes)
-    if (A.kind == K_HULL) for (int f = 0; f < A.hull.hf; ++f) { double fn[3]; hull_face_normal(A, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
-    if (Bc.kind == K_HULL) for (int f = 0; f < Bc.hull.hf; ++f) { double fn[3]; hull_face_normal(Bc, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
+    if (A.kind == K_HULL) for (int f = 0, nf = hull_hf(A); f < nf; ++f) { double fn[3]; hull_face_normal(A, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
+    if (Bc.kind == K_HULL) for (int f = 0, nf = hull_hf(Bc); f < nf; ++f) { double fn[3]; hull_face_normal(Bc, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
     if (A.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A.ax[2]), A.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
     if (Bc.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc.ax[2]), Bc.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
     try_axis(A, Bc, delta, delta, best, normal);
     if (best == NBK_INF) best = 0.0;
     return best;
+}
+
+__device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc) {
+    double nrm[3];
+    return overlap_depth(A, Bc, nrm);
 }
 
 // ---- closed forms for point / segment cores ---------------------------------------------------
@@ -972,7 +1008,7 @@ NBK_DEV bool plane_collides(const Core& A, const Core& Pl, double thr, double rh
 // bounding box, so a centre farther than tc + rho from that box means a core distance of at least tc -- free.  The comparison keeps a
 // 1e-9 relative margin so that it can never contradict what the GJK iteration of the oracle decides in its last digits.
 NBK_DEV bool hull_box_far(const double* c, double rho, const Core& H, double tc) {
-    const double* ob = H.hull.hv - 6;
+    const double* ob = hull_hv(H) - 6;
     double d[3];
     sub3(c, H.c, d);
     double d2 = 0.0;
@@ -1033,6 +1069,10 @@ NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
     const int pre = cores_collide_pre(A, Bc, tc);
     if (pre >= 0) return pre != 0;
     if (tc == 0.0) return gjk_intersect(A, Bc);       // pure intersection test: the boolean walk
+    if (tc > 0.0) {                                   // the same walk on the inflated core; the distance iteration if it gives up
+        const int r = gjk_intersect_inflated(A, Bc, tc);
+        if (r >= 0) return r != 0;
+    }
     return gjk_collides(A, Bc, tc);
 }
 

@@ -674,7 +674,15 @@ static double overlap_depth(const core_t *A, const core_t *Bc, double *normal);
 
 /* GJK predicate: is dist(coreA, coreB) < tc ?  Same iteration as gjk_cores, but it stops as soon as the
  * support-plane lower bound reaches tc (free) or the simplex point drops below tc (colliding). */
+static __thread long long g_pred_hist[80];       /* iterations of gjk_collides (diagnostic) */
+static int gjk_collides_it(const core_t *A, const core_t *Bc, double tc, int *iters);
 static int gjk_collides(const core_t *A, const core_t *Bc, double tc) {
+    int it = 0;
+    const int r = gjk_collides_it(A, Bc, tc, &it);
+    g_pred_hist[it < 79 ? it : 79] += 1;
+    return r;
+}
+static int gjk_collides_it(const core_t *A, const core_t *Bc, double tc, int *iters) {
     simplex_t sx;
     sx.n = 0;
     double v[3];
@@ -684,6 +692,7 @@ static int gjk_collides(const core_t *A, const core_t *Bc, double tc) {
     const double tc2 = tc * tc;
     int sep = 0;
     for (int it = 0; it < GJK_MAXIT; ++it) {
+        *iters = it + 1;
         double nv[3] = {-v[0], -v[1], -v[2]};
         double sa[3], sb[3], w[3];
         core_support(A, nv, sa);
@@ -1024,10 +1033,21 @@ static void gjkb_init(gjkb_t *g, const core_t *A, const core_t *Bc) {
     g->it = 0;
 }
 /* one iteration: 0 = continue, 1 = free, 2 = intersecting */
-static int gjkb_step(gjkb_t *g, const core_t *A, const core_t *Bc) {
-    if (g->it >= GJKB_MAXIT) return 2;
+/* infl (tc > 0): core A is inflated by a ball of radius tc -- its support point moves by tc d/|d| -- so the same walk decides
+ * dist(A, B) < tc.  A rounded shape can need many steps to separate from a near-tangent partner (cylinder pairs a few 1e-4
+ * apart: up to 38 steps seen in 1e6 configurations of the benchmark scene, where the sharp-shape walk needs 8); with the cap at
+ * 64 nothing was left undecided there, with 20 some 10-2000 pairs per 1e6 configurations.  An undecided walk (cap reached, or
+ * the origin on the simplex) returns 3 and cores_collide falls back to gjk_collides, so the predicate stays exact. */
+#define GJKB_INFL_MAXIT 64
+static int gjkb_step(gjkb_t *g, const core_t *A, const core_t *Bc, double tc) {
+    const int infl = tc > 0.0;
+    if (g->it >= (infl ? GJKB_INFL_MAXIT : GJKB_MAXIT)) return infl ? 3 : 2;
     double a[3];
     mink_support(A, Bc, g->d, a);
+    if (infl) {
+        const double k = tc / sqrt(dot3(g->d, g->d));
+        axpy3(k, g->d, a, a);
+    }
     if (dot3(a, g->d) < 0.0) return 1;
     g->it += 1;
     if (g->n == 0) {
@@ -1057,17 +1077,38 @@ static int gjkb_step(gjkb_t *g, const core_t *A, const core_t *Bc) {
         else if (sadb * dot3(adb, ao) > 0.0) gjkb_triangle(g, b, dd, a);
         else return 2;
     }
-    if (dot3(g->d, g->d) == 0.0) return 2;      /* the origin lies on the simplex */
+    if (dot3(g->d, g->d) == 0.0) return infl ? 3 : 2;      /* the origin lies on the simplex */
     return 0;
 }
 static __thread long long g_gjkb_hist[40];       /* iterations of the boolean walk, per verdict (diagnostic) */
 static int gjk_intersect(const core_t *A, const core_t *Bc) {
     gjkb_t g;
     gjkb_init(&g, A, Bc);
-    for (;;) { const int r = gjkb_step(&g, A, Bc); if (r) { g_gjkb_hist[g.it < 39 ? g.it : 39] += 1; return r == 2; } }
+    for (;;) { const int r = gjkb_step(&g, A, Bc, 0.0); if (r) { g_gjkb_hist[g.it < 39 ? g.it : 39] += 1; return r == 2; } }
+}
+/* dist(A, B) < tc for tc > 0 by the inflated walk: 1 colliding, 0 free, -1 undecided */
+static __thread long long g_infl_undecided = 0, g_infl_calls = 0;
+static __thread long long g_infl_hist[40];
+static int gjk_intersect_inflated(const core_t *A, const core_t *Bc, double tc) {
+    gjkb_t g;
+    gjkb_init(&g, A, Bc);
+    g_infl_calls++;
+    for (;;) {
+        const int r = gjkb_step(&g, A, Bc, tc);
+        if (r == 3) {
+            g_infl_undecided++; g_infl_hist[39] += 1;
+            return -1;
+        }
+        if (r) { g_infl_hist[g.it < 38 ? g.it : 38] += 1; return r == 2; }
+    }
 }
 void orc_gjkb_hist(long long *out, int reset) {
     for (int i = 0; i < 40; ++i) { out[i] = g_gjkb_hist[i]; if (reset) g_gjkb_hist[i] = 0; }
+}
+/* out[80]: iterations of the distance predicate; out[80..119]: of the inflated walk (entry 39 = undecided) */
+void orc_pred_hist(long long *out, int reset) {
+    for (int i = 0; i < 80; ++i) { out[i] = g_pred_hist[i]; if (reset) g_pred_hist[i] = 0; }
+    for (int i = 0; i < 40; ++i) { out[80 + i] = g_infl_hist[i]; if (reset) g_infl_hist[i] = 0; }
 }
 
 /* bounding radius of a core about its centre (broadphase) */
@@ -1095,7 +1136,9 @@ static __thread long long g_stat_items = 0, g_stat_survive = 0, g_stat_gjk = 0; 
  *      square roots: d2 = squared distance of c to the box; outside: d2 >= (tc + rho_other)^2 (tc >= 0) => free,
  *      d2 < tc^2 (tc > 0) => colliding; inside at depth g: -g < tc => colliding;
  *   5. exact test: closed form for point/segment cores and point-vs-solid; otherwise GJK -- the boolean walk
- *      (gjk_intersect) when tc == 0, the distance iteration with early exits (gjk_collides) for any other tc. */
+ *      (gjk_intersect) when tc == 0; for tc > 0 the same walk with core A inflated by a ball of radius tc
+ *      (gjk_intersect_inflated: "A (+) ball(tc) meets B" is "dist < tc"), and the distance iteration with early exits
+ *      (gjk_collides) for tc < 0 and for the few pairs the inflated walk leaves undecided after 20 steps. */
 static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     if (B0->kind == K_PLANE) {
         double d[3];
@@ -1155,7 +1198,11 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     if (A->kind == K_POINT && Bc->kind != K_HULL) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
     g_stat_gjk++;
     if (tc == 0.0) return gjk_intersect(A, Bc);      /* pure intersection test: the boolean walk */
-    return gjk_collides(A, Bc, tc);
+    if (tc > 0.0) {                                  /* the same walk with core A inflated by tc ... */
+        const int r = gjk_intersect_inflated(A, Bc, tc);
+        if (r >= 0) return r;
+    }
+    return gjk_collides(A, Bc, tc);                  /* ... and the distance iteration for tc < 0 or an undecided walk */
 }
 
 /* diagnostic: one pair of one configuration, with the walk of either predicate printed (tools/fuzz_repro.py) */
@@ -1194,7 +1241,7 @@ int orc_pair_trace(const orc_model *m, const double *q, int32_t p, double thr) {
           double r[3]; sub3(sa, A->c, r);
           fprintf(stderr, "      d %.17g %.17g %.17g | sa-c axial %.17g |sa-c| %.17g  d.u %.17g\n", g.d[0], g.d[1], g.d[2], dot3(r, A->ax[2]), sqrt(dot3(r, r)), dot3(g.d, A->ax[2])); }
         for (int i = 0; i < g.n; ++i) fprintf(stderr, "      p%d (%.9g %.9g %.9g)\n", i, g.p[i][0], g.p[i][1], g.p[i][2]);
-        const int r = gjkb_step(&g, A, Bc);
+        const int r = gjkb_step(&g, A, Bc, 0.0);
         if (r) { fprintf(stderr, "  boolean walk: verdict %d after %d iterations\n", r, g.it); break; }
     }
     fprintf(stderr, "  gjk_collides(tc) = %d, cores_collide = %d\n", gjk_collides(A, Bc, tc), cores_collide(A, Bc, thr));
@@ -1203,8 +1250,8 @@ int orc_pair_trace(const orc_model *m, const double *q, int32_t p, double thr) {
 }
 
 void orc_stats(long long *out, int reset) {
-    out[0] = g_stat_items; out[1] = g_stat_survive; out[2] = g_stat_gjk;
-    if (reset) { g_stat_items = g_stat_survive = g_stat_gjk = 0; }
+    out[0] = g_stat_items; out[1] = g_stat_survive; out[2] = g_stat_gjk; out[3] = g_infl_calls; out[4] = g_infl_undecided;
+    if (reset) { g_stat_items = g_stat_survive = g_stat_gjk = 0; g_infl_calls = g_infl_undecided = 0; }
 }
 
 double orc_shape_distance_m(const orc_model *hulls, int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,

@@ -124,9 +124,11 @@ double orc_shape_distance_m(const orc_model *hulls, int32_t type_a, const double
 int orc_shape_collides_m(const orc_model *hulls, int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
                          const double *pose_b, const double *param_b, double threshold);
 
-/* broadphase statistics of the predicate since the last reset: items, survivors of the sphere test, GJK calls
- * (single-threaded runs only; not synchronised) */
+/* statistics of the predicate since the last reset, out[5]: items, survivors of the sphere test, GJK calls, inflated walks,
+ * inflated walks left undecided (per thread: meaningful after single-threaded runs only) */
 void orc_stats(long long *out, int reset);
+/* out[120]: iterations of the distance predicate [0..79], of the inflated walk [80..118], undecided inflated walks [119] */
+void orc_pred_hist(long long *out, int reset);
 
 /* the validity predicate of one pair: signed distance < threshold, decided with early outs */
 int orc_shape_collides(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
