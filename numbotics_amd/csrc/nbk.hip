@@ -2479,11 +2479,13 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 // on everything); with 64 none does on the benchmark scene and the tail is the walk's own 38 steps (66 us).
                 GjkBool gb;
                 gjkb_init(gb, A, Bc);
-                bool hard = false;
+                // hull cores skip the walk: every step scans a vertex list and the distance iteration needs half as many
+                bool hard = have && (A.kind == K_HULL || Bc.kind == K_HULL);
+                have = have && !hard;
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
                         const int r = gjkb_step<1>(gb, A, Bc, tc);
-                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); hard = r == 3; have = false; }
+                        if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); hard = hard || r == 3; have = false; }
                     }
                 }
                 if (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
@@ -2510,7 +2512,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 GjkPred g;
                 gjkb_init(gb, A, Bc);
                 gjk_pred_init(g, A, Bc);
-                bool walk = tc >= 0.0;                   // (a NaN threshold takes the distance iteration, as before)
+                bool walk = tc == 0.0 || (tc > 0.0 && A.kind != K_HULL && Bc.kind != K_HULL);    // (a NaN threshold takes the distance iteration)
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
                         const int r = walk ? gjkb_step<2>(gb, A, Bc, tc) : gjk_pred_step(g, A, Bc, tc);
