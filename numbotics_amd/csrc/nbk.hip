@@ -151,6 +151,7 @@ struct nbk_model {
     std::vector<int> h_cat, h_cls;
     std::vector<int> h_joint_qidx, h_joint_type;   // host copies for make_path
     std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
+    bool gjk_any_hull = false;         // ... and whether one of them has a hull core (those always take the distance iteration)
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
     bool margins_zero;        // every pair that can reach GJK (no point core, not point/segment x point/segment) has mA = mB = 0:
@@ -2333,10 +2334,11 @@ NBK_DEV void mark_hit(long long b, uint64_t* mask_bits, uint8_t* mask_bytes) {
 __device__ unsigned long long g_narrow_prof[16];
 #define NBK_STAMP(i) do { if (prof) { __builtin_amdgcn_s_waitcnt(0); stamp[i] = __builtin_readcyclecounter(); } } while (0)
 
-// MODE 0: any mix of tc (per item: tc >= 0 walks the boolean GJK, inflated by tc when tc > 0, tc < 0 runs the distance
-// predicate), 1: tc == 0 for every pair that can reach GJK -- boolean walk only, 2: tc < 0 everywhere -- distance predicate
-// only, 3: tc > 0 everywhere (a positive threshold such as IRIS' 1e-6, or a margin on every solid) -- inflated walk, then the
-// distance predicate for what it leaves undecided
+// MODE 0: any mix of tc (per item: tc >= 0 without a hull core walks the boolean GJK, inflated by tc when tc > 0; tc < 0 and hull
+// pairs run the distance predicate), 1: tc == 0 for every pair that can reach GJK and none has a hull core -- boolean walk
+// only, 2: tc < 0 everywhere -- distance predicate only, 3: tc >= 0 everywhere (a positive threshold such as IRIS' 1e-6, a
+// margin on every solid, or threshold 0 on a scene with meshes) -- the walk, then the distance predicate for hull pairs and for
+// what an inflated walk leaves undecided
 template <int MODE>
 NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __restrict__ q, double thr,
                          const unsigned long long* __restrict__ q_items, unsigned long long* q_count,
@@ -2484,7 +2486,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 have = have && !hard;
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
-                        const int r = gjkb_step<1>(gb, A, Bc, tc);
+                        const int r = gjkb_step<2>(gb, A, Bc, tc);
                         if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); hard = hard || r == 3; have = false; }
                     }
                 }
@@ -2493,7 +2495,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                     gjk_pred_init(g, A, Bc);
                     while (__builtin_amdgcn_ballot_w64(hard) != 0ull) {
                         if (hard) {
-                            const int r = gjk_pred_step<true>(g, A, Bc, tc);
+                            const int r = gjk_pred_step<true>(g, A, Bc, tc);      // (<true>: tc >= 0 here, no overlap-depth estimate)
                             if (r != 0) { if (r == 2) mark_hit(b, mask_bits, mask_bytes); hard = false; }
                         }
                     }
@@ -2512,7 +2514,7 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
                 GjkPred g;
                 gjkb_init(gb, A, Bc);
                 gjk_pred_init(g, A, Bc);
-                bool walk = tc == 0.0 || (tc > 0.0 && A.kind != K_HULL && Bc.kind != K_HULL);    // (a NaN threshold takes the distance iteration)
+                bool walk = tc >= 0.0 && A.kind != K_HULL && Bc.kind != K_HULL;    // (a NaN threshold takes the distance iteration)
                 while (__builtin_amdgcn_ballot_w64(have) != 0ull) {
                     if (have) {
                         const int r = walk ? gjkb_step<2>(gb, A, Bc, tc) : gjk_pred_step(g, A, Bc, tc);
@@ -3188,6 +3190,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     std::vector<double> vp_cst(4 * (size_t)P), ws_center(3 * (size_t)W);
     bool margins_zero = true;
     std::vector<double> gjk_margins;
+    bool gjk_any_hull = false;
     for (int i = 0; i < P; ++i) {
         const int p = vorder[i];
         const int ka = kind_of(refA[p]), kb = kind_of(refB[p]);
@@ -3204,7 +3207,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
             const int k0 = ka < kb ? ka : kb, k1 = ka < kb ? kb : ka;          // canonical order
             const bool closed = k1 != K_HULL && (k0 == K_POINT || ((k0 == K_POINT || k0 == K_SEG) && (k1 == K_POINT || k1 == K_SEG)));
             if (k1 != K_PLANE && !closed && (ca[4] != 0.0 || cb[4] != 0.0)) margins_zero = false;
-            if (k1 != K_PLANE && !closed) { gjk_margins.push_back(ca[4]); gjk_margins.push_back(cb[4]); }
+            if (k1 != K_PLANE && !closed) { gjk_margins.push_back(ca[4]); gjk_margins.push_back(cb[4]); if (k1 == K_HULL) gjk_any_hull = true; }
         }
     }
     for (int w = 0; w < W; ++w) { ws_center[3 * w] = ws_core[18 * w]; ws_center[3 * w + 1] = ws_core[18 * w + 1]; ws_center[3 * w + 2] = ws_core[18 * w + 2]; }
@@ -3554,6 +3557,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         M->h_cat[j] = bq_tab[4 * j + 3]; M->h_cls[j] = vp_cls[i];
     }
     M->gjk_margins = gjk_margins;
+    M->gjk_any_hull = gjk_any_hull;
     M->lds_broad_ok = lds_broad_ok;
     M->parked_ok = parked_ok;
     (void)hipGetDevice(&M->device);
@@ -3912,8 +3916,9 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         NBK_HIP(hipEventRecord(iw0->ev_fork, st0));                          // the odd tiles' inputs are whatever the caller's stream has produced
         NBK_HIP(hipStreamWaitEvent(iw0->aux_stream, iw0->ev_fork, 0));
     }
-    // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero -> boolean walk only, all positive -> the
-    // inflated walk (+ fallback), all negative -> distance predicate only, else the build with both
+    // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero and no hull -> boolean walk only, none negative ->
+    // the (inflated) walk + the distance iteration for hulls and undecided walks, all negative -> distance predicate only, else
+    // the build with everything
     bool any_zero = false, any_positive = false, any_negative = false;
     for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
         const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
@@ -3988,9 +3993,9 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         unsigned parts = 4u * nblk / NSUB;
         { const unsigned pmax = g_opt.narrow_parts_max > 0 ? (unsigned)g_opt.narrow_parts_max : 16u; parts = parts < 4u ? 4u : parts; parts = parts > pmax ? pmax : parts; }
         if (nblk <= 4u) parts = 1u;                      // a handful of configurations (the scalar calls): 256 workgroups are plenty
-        if (!any_positive && !any_negative)
+        if (!any_positive && !any_negative && !m->gjk_any_hull)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
-        else if (!any_zero && !any_negative)
+        else if (!any_negative)
             hipLaunchKernelGGL(k_narrow_pos, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else if (!any_zero && !any_positive)
             hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);

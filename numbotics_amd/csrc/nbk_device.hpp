@@ -1067,11 +1067,13 @@ NBK_DEV int cores_collide_pre(const Core& A, const Core& Bc, double tc) {
 NBK_DEV bool cores_collide_exact(const Core& A, const Core& Bc, double tc) {
     const int pre = cores_collide_pre(A, Bc, tc);
     if (pre >= 0) return pre != 0;
-    if (tc == 0.0) return gjk_intersect(A, Bc);       // pure intersection test: the boolean walk
-    if (tc > 0.0 && A.kind != K_HULL && Bc.kind != K_HULL) {   // the same walk on the inflated core; the distance iteration if it gives up
+    if (A.kind != K_HULL && Bc.kind != K_HULL) {
         // (hull cores go straight to the distance iteration: its early exits halve the number of vertex-list scans)
-        const int r = gjk_intersect_inflated(A, Bc, tc);
-        if (r >= 0) return r != 0;
+        if (tc == 0.0) return gjk_intersect(A, Bc);   // pure intersection test: the boolean walk
+        if (tc > 0.0) {                               // the same walk on the inflated core; the distance iteration if it gives up
+            const int r = gjk_intersect_inflated(A, Bc, tc);
+            if (r >= 0) return r != 0;
+        }
     }
     return gjk_collides(A, Bc, tc);
 }

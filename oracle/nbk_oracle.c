@@ -1136,9 +1136,10 @@ static __thread long long g_stat_items = 0, g_stat_survive = 0, g_stat_gjk = 0; 
  *      square roots: d2 = squared distance of c to the box; outside: d2 >= (tc + rho_other)^2 (tc >= 0) => free,
  *      d2 < tc^2 (tc > 0) => colliding; inside at depth g: -g < tc => colliding;
  *   5. exact test: closed form for point/segment cores and point-vs-solid; otherwise GJK -- the boolean walk
- *      (gjk_intersect) when tc == 0; for tc > 0 (and no hull core) the same walk with core A inflated by a ball of radius tc
+ *      (gjk_intersect) when tc == 0; for tc > 0 the same walk with core A inflated by a ball of radius tc
  *      (gjk_intersect_inflated: "A (+) ball(tc) meets B" is "dist < tc"), and the distance iteration with early exits
- *      (gjk_collides) for tc < 0 and for the few pairs the inflated walk leaves undecided after 20 steps. */
+ *      (gjk_collides) for tc < 0, for every pair with a hull core, and for the few pairs the inflated walk leaves
+ *      undecided after 64 steps. */
 static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     if (B0->kind == K_PLANE) {
         double d[3];
@@ -1197,11 +1198,13 @@ static int cores_collide(const core_t *A0, const core_t *B0, double thr) {
     }
     if (A->kind == K_POINT && Bc->kind != K_HULL) { double cp[3], nb[3]; return point_solid(A->c, Bc, cp, nb) < tc; }
     g_stat_gjk++;
-    if (tc == 0.0) return gjk_intersect(A, Bc);      /* pure intersection test: the boolean walk */
-    if (tc > 0.0 && A->kind != K_HULL && Bc->kind != K_HULL) {       /* the same walk with core A inflated by tc ... */
+    if (A->kind != K_HULL && Bc->kind != K_HULL) {
         /* (not for hulls: every step scans a vertex list, and the distance iteration's early exits need half as many steps) */
-        const int r = gjk_intersect_inflated(A, Bc, tc);
-        if (r >= 0) return r;
+        if (tc == 0.0) return gjk_intersect(A, Bc);  /* pure intersection test: the boolean walk */
+        if (tc > 0.0) {                              /* the same walk with core A inflated by tc ... */
+            const int r = gjk_intersect_inflated(A, Bc, tc);
+            if (r >= 0) return r;
+        }
     }
     return gjk_collides(A, Bc, tc);                  /* ... and the distance iteration for tc < 0 or an undecided walk */
 }
