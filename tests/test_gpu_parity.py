@@ -748,6 +748,35 @@ def test_contact_transitions_are_resolved_exactly(fresh_world, scene, torch_cuda
         assert np.array_equal(arm.in_collision(q, thr), orc.validity(q, thr, nthreads=8))
 
 
+def test_thresholds_at_the_distance_itself(fresh_world, torch_cuda):
+    """Positive thresholds within 1e-9 (relative) of a configuration's own clearance: the inflated boolean walk cannot decide
+    these in 64 steps when the closest pair is curved, and the distance iteration has to -- on the device (k_narrow_pos and the
+    fused kernel) as in the oracle, whose counter confirms the fallback was taken."""
+    import ctypes
+    from oracle.cpu_oracle import lib as orc_lib
+    arm, chain, obs = build_scene("c2")
+    orc = Oracle(arm.scene_model())
+    base = sample_q(chain, 6000, seed=91)
+    dmin = np.asarray(orc.pair_distances(base)).min(axis=1)
+    sel = np.nonzero((dmin > 2e-3) & (dmin < 0.25))[0][:250]
+    assert len(sel) >= 200
+    stats = (ctypes.c_longlong * 8)()
+    orc_lib().orc_stats(stats, 1)
+    n_checked = 0
+    for i in sel:
+        q = np.repeat(base[i:i + 1], 64, axis=0)
+        for f in (1.0 - 1e-9, 1.0, 1.0 + 1e-9):
+            thr = float(dmin[i] * f)
+            ref = bool(orc.validity(base[i:i + 1], thr)[0])
+            got = np.asarray(arm.in_collision(q, thr))
+            assert got.all() == got.any() and bool(got[0]) == ref, (i, f, thr)
+            with fused_path():
+                assert bool(np.asarray(arm.in_collision(q[:2], thr))[0]) == ref, (i, f, thr, "fused")
+            n_checked += 1
+    orc_lib().orc_stats(stats, 0)
+    assert stats[3] > 0 and stats[4] > 0, ("inflated walks / undecided", stats[3], stats[4], n_checked)
+
+
 def test_broadphase_boundary_on_sphere_pairs(fresh_world, torch_cuda):
     """Sphere link against sphere obstacles: the shapes fill their bounding spheres, so the contact transition IS the
     boundary of the broadphase's bounding-sphere test -- the place where a non-conservative float32 cull would show."""
