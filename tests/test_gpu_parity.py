@@ -107,10 +107,12 @@ def test_jacobian_bitwise_and_golden(kinova, g3, golden_meta, torch_cuda):
     assert np.array_equal(arm.jacobian(q[:4], "base_link"), np.zeros((4, 6, 7)))  # arm.py:455-457
 
 
-@pytest.mark.parametrize("scene", ["c2", "c3"])
+@pytest.mark.parametrize("scene", ["c1", "c2", "c3"])
 def test_validity_mask_bitwise(fresh_world, scene, torch_cuda):
+    """c1: the arm alone (self-collision pairs only, no world shape at all), c2 / c3: BASELINE configs 2 and 3."""
     arm, chain, obs = build_scene(scene)
     sm = arm.scene_model()
+    assert (sm.n_wshapes == 0) == (scene == "c1")
     orc = Oracle(sm)
     q = sample_q(chain, 20000, seed=2)
     for thr in (0.0, 1e-6, 0.02, -0.005):
@@ -118,7 +120,9 @@ def test_validity_mask_bitwise(fresh_world, scene, torch_cuda):
         ref = orc.validity(q, thr)
         assert mask.dtype == bool and mask.shape == (20000,)
         assert np.array_equal(mask, ref), (scene, thr, int((mask != ref).sum()))
-    assert 0.01 < orc.validity(q, 0.0).mean() < 0.9
+        with fused_path():
+            assert np.array_equal(arm.in_collision(q[:3000], thr), ref[:3000]), (scene, thr, "fused")
+    assert 0.005 < orc.validity(q, 0.0).mean() < 0.9
     # packed bit mask == bytes
     _, dev = arm._scene_device()
     words = dev.validity(q, 0.0, packed=True)
