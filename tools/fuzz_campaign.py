@@ -2,7 +2,8 @@
 several thresholds, device masks (two-kernel path with the float32 broadphase) against the CPU oracle.
     python tools/fuzz_campaign.py [first_seed] [n_seeds] [configs_per_seed]
 Every third seed builds its robot and obstacles WITH MESHES (random polytope files, scaled / offset / auto-centred / compound),
-every fourth compiles the scene with bullet_margins=True; NBK_FUZZ_ALL=1 adds every other entry point."""
+every fourth compiles the scene with bullet_margins=True; NBK_FUZZ_ALL=1 adds every other entry point,
+NBK_FUZZ_THRESHOLDS="0.05,0.2,-0.01,1e-3" replaces the four default thresholds."""
 import os, sys, tempfile, numpy as np
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -15,6 +16,7 @@ build()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 60000
+THRESHOLDS = tuple(float(x) for x in os.environ.get("NBK_FUZZ_THRESHOLDS", "0,0.01,-0.002,1e-6").split(","))
 bad = 0
 total = 0
 with tempfile.TemporaryDirectory() as d:
@@ -36,7 +38,7 @@ with tempfile.TemporaryDirectory() as d:
         lim = np.where(np.isfinite(lim), lim, np.sign(lim) * np.pi)
         q = rng.uniform(lim[:, 0], lim[:, 1], (B, chain.dof))
         line = f"seed {seed}: links {n_links} dof {chain.dof} shapes {sm.n_rshapes}+{sm.n_wshapes} pairs {sm.n_pairs} hulls {sm.n_hulls}" + (" bullet-margins" if seed % 4 == 0 else "")
-        for thr in (0.0, 0.01, -0.002, 1e-6):
+        for thr in THRESHOLDS:
             ref = orc.validity(q, thr, nthreads=16)
             got = np.asarray(arm.in_collision(q, thr))
             nbad = int((ref != got).sum())
