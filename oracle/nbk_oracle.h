@@ -129,6 +129,9 @@ int orc_shape_collides_m(const orc_model *hulls, int32_t type_a, const double *p
 void orc_stats(long long *out, int reset);
 /* out[120]: iterations of the distance predicate [0..79], of the inflated walk [80..118], undecided inflated walks [119] */
 void orc_pred_hist(long long *out, int reset);
+/* diagnostic: the cores of pair `p` at configuration q, the distance both ways round and the walk of both predicates, to stderr
+ * (tools/fuzz_repro.py, Oracle.pair_trace) */
+int orc_pair_trace(const orc_model *m, const double *q, int32_t p, double thr);
 
 /* the validity predicate of one pair: signed distance < threshold, decided with early outs */
 int orc_shape_collides(int32_t type_a, const double *pose_a, const double *param_a, int32_t type_b,
