@@ -49,6 +49,8 @@ struct DevModel {
     const double* rs_core;        // [S][6] h0 h1 h2 rad margin rho
     const int* ws_kind;           // [W]
     const double* ws_core;        // [W][18] c(3) ax(9: ax0 ax1 ax2) h(3) rad margin rho
+    const double* hull_blob;      // every hull's [bounding box (6) | vertices (3 n)], back to back: what the HullRef.hv pointers point into
+    int hull_blob_n;              // ... in doubles; k_narrow* stage it in LDS when it is at most HULL_LDS_MAX bytes
     const int* pair_a;            // [P] index into rs_* (frame order)
     const int* pair_b;            // [P] < S robot (frame order), else S + world
     const int* pair_user;         // [P] index of this pair in the caller's pair list
@@ -2316,6 +2318,10 @@ NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
 //            lanes new items existed while chunks were larger than the wave; with 64-item chunks it never had
 //            anything left to hand out and only cost 18 KB of LDS per workgroup.
 constexpr int NARROW_T = 64;
+constexpr int HULL_LDS_MAX = 16 * 1024;   // k_narrow*: the scene's hull vertices live in LDS when they fit this (the per-lane vertex loop of
+                                          // the hull support is 3 loads per vertex at lane-varying addresses: LDS serves those several
+                                          // times faster than the vector memory path)
+static inline size_t narrow_hull_lds(int hull_blob_n) { return (hull_blob_n > 0 && (size_t)hull_blob_n * 8 <= (size_t)HULL_LDS_MAX) ? (size_t)hull_blob_n * 8 : 0; }
 #ifndef NARROW_WAVES_GEN
 #define NARROW_WAVES_GEN 2
 #endif
@@ -2368,6 +2374,13 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
     // workgroup held up by a slow item (a GJK walk of 30+ steps where 5 are usual) takes fewer chunks instead of finishing its fixed
     // share late -- the kernel ends with its slowest workgroup.  The next ticket is drawn before the current chunk is worked on.
     unsigned long long* ticket = q_count + sub * CNT_STRIDE + CNT_TICKET;
+    // hull vertices into LDS (workgroups with work only); the cores' HullRef.hv pointers are redirected after build_core
+    double* hull_lds = qstage + NARROW_T * m.n_q;
+    const bool hull_staged = m.hull_blob_n > 0 && m.hull_blob_n * 8 <= HULL_LDS_MAX;
+    if (hull_staged && (unsigned long long)part * NARROW_T < n) {
+        for (int i = threadIdx.x; i < m.hull_blob_n; i += NARROW_T) hull_lds[i] = m.hull_blob[i];
+        __syncthreads();
+    }
     for (unsigned long long chunk = part; chunk * NARROW_T < n; ) {
         const unsigned long long i0 = chunk * NARROW_T;
         unsigned next_ticket = 0u;
@@ -2443,6 +2456,10 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             if (live && !(NBK_DBG(m) & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
+                if (hull_staged) {
+                    if (A.kind == K_HULL) A.h[0] = __builtin_bit_cast(double, reinterpret_cast<unsigned long long>(hull_lds + (hull_hv(A) - m.hull_blob)));
+                    if (Bc.kind == K_HULL) Bc.h[0] = __builtin_bit_cast(double, reinterpret_cast<unsigned long long>(hull_lds + (hull_hv(Bc) - m.hull_blob)));
+                }
                 if (prof) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; if (acc == 12345.678) mark_hit(b, mask_bits, mask_bytes); }
                 NBK_STAMP(4);
                 const double* cst = m.vp_cst + 4 * p;
@@ -3507,6 +3524,8 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.rs_core = reinterpret_cast<const double*>(base + o.rc);
     m.ws_kind = reinterpret_cast<const int*>(base + o.wk);
     m.ws_core = reinterpret_cast<const double*>(base + o.wc);
+    m.hull_blob = reinterpret_cast<const double*>(base + o_hv);
+    m.hull_blob_n = (int)hull_blob.size();
     m.pair_a = reinterpret_cast<const int*>(base + o.pa);
     m.pair_b = reinterpret_cast<const int*>(base + o.pb);
     m.pair_user = reinterpret_cast<const int*>(base + o.pu);
@@ -3988,7 +4007,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         else
             hipLaunchKernelGGL(k_broad, dim3(nblk), dim3(WAVE), broad_lds(m), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         NBK_HIP(hipGetLastError());
-        const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q;
+        const size_t nlds = sizeof(double) * NARROW_T * (size_t)m->n_q + narrow_hull_lds(m->d.hull_blob_n);
         // workgroups per sub-queue: one 64-item chunk each at a few survivors per configuration; more chunks are strided over
         unsigned parts = 4u * nblk / NSUB;
         { const unsigned pmax = g_opt.narrow_parts_max > 0 ? (unsigned)g_opt.narrow_parts_max : 16u; parts = parts < 4u ? 4u : parts; parts = parts > pmax ? pmax : parts; }
