@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage (GPU box): bash tools/scene_prof.sh   -- per-kernel averages of the validity step on the compound-mesh scene c5m
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof_c5m
 timeout -k 5 150 rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 tools/variant_time.py numbotics_amd/csrc/libnbk.so c5m > "$out.log" 2>&1 < /dev/null
