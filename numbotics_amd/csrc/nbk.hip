@@ -2456,9 +2456,10 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             if (live && !(NBK_DBG(m) & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
-                if (hull_staged) {
-                    if (A.kind == K_HULL) A.h[0] = __builtin_bit_cast(double, reinterpret_cast<unsigned long long>(hull_lds + (hull_hv(A) - m.hull_blob)));
-                    if (Bc.kind == K_HULL) Bc.h[0] = __builtin_bit_cast(double, reinterpret_cast<unsigned long long>(hull_lds + (hull_hv(Bc) - m.hull_blob)));
+                if (hull_staged) {       // the support routine reads the vertices at the LDS address in `rad`; everything else keeps HullRef.hv
+                    const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double*)hull_lds);
+                    if (A.kind == K_HULL) A.rad = (double)(lds0 + 8u * (unsigned)(hull_hv(A) - m.hull_blob));
+                    if (Bc.kind == K_HULL) Bc.rad = (double)(lds0 + 8u * (unsigned)(hull_hv(Bc) - m.hull_blob));
                 }
                 if (prof) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; if (acc == 12345.678) mark_hit(b, mask_bits, mask_bytes); }
                 NBK_STAMP(4);

@@ -122,6 +122,42 @@ NBK_DEV const double* hull_hp(const Core& s) { return reinterpret_cast<const dou
 NBK_DEV int hull_hn(const Core& s) { return (int)(unsigned)(__builtin_bit_cast(unsigned long long, s.h[2]) & 0xFFFFFFFFull); }
 NBK_DEV int hull_hf(const Core& s) { return (int)(unsigned)(__builtin_bit_cast(unsigned long long, s.h[2]) >> 32); }
 
+typedef const __attribute__((address_space(3))) double* LdsDoubleP;
+// four vertices per trip: their twelve loads are issued together (per-lane loads in k_narrow, where the lanes of a wave hold
+// different hulls), the comparisons stay in vertex order
+template <typename P>
+NBK_DEV void hull_first_max(P hv, int hn, double dl0, double dl1, double dl2, double& v0, double& v1, double& v2) {
+    double best = -NBK_INF;
+    int bi = 0;
+    int k = 0;
+    for (; k + 4 <= hn; k += 4) {
+        double vx[4], vy[4], vz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { vx[u] = hv[3 * (k + u)]; vy[u] = hv[3 * (k + u) + 1]; vz[u] = hv[3 * (k + u) + 2]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double pr = NBK_FMA(vz[u], dl2, NBK_FMA(vy[u], dl1, vx[u] * dl0));
+            if (pr > best) { best = pr; bi = k + u; }
+        }
+    }
+    for (; k < hn; ++k) {
+        const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
+        if (pr > best) { best = pr; bi = k; }
+    }
+    v0 = hv[3 * bi]; v1 = hv[3 * bi + 1]; v2 = hv[3 * bi + 2];
+}
+
+template <typename P>
+NBK_DEV void hull_min_max(P hv, int hn, double dl0, double dl1, double dl2, double& neg, double& pos) {
+    double hi = -NBK_INF, lo = NBK_INF;
+    for (int k = 0; k < hn; ++k) {
+        const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
+        if (pr > hi) hi = pr;
+        if (pr < lo) lo = pr;
+    }
+    pos = hi; neg = -lo;
+}
+
 NBK_DEV void core_support(const Core& s, const double* d, double* o) {
     switch (s.kind) {
         case K_POINT: copy3(s.c, o); break;
@@ -152,29 +188,12 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
         case K_HULL: {
             // direction in local coordinates, first maximum over the vertex list, that vertex back to the world
             const double dl0 = dot3(d, s.ax[0]), dl1 = dot3(d, s.ax[1]), dl2 = dot3(d, s.ax[2]);
-            const double* hv = hull_hv(s);
             const int hn = hull_hn(s);
-            double best = -NBK_INF;
-            int bi = 0;
-            // four vertices per trip: their twelve loads are issued together (per-lane loads in k_narrow, where the lanes of a wave
-            // hold different hulls), the comparisons stay in vertex order
-            int k = 0;
-            for (; k + 4 <= hn; k += 4) {
-                double vx[4], vy[4], vz[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { vx[u] = hv[3 * (k + u)]; vy[u] = hv[3 * (k + u) + 1]; vz[u] = hv[3 * (k + u) + 2]; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double pr = NBK_FMA(vz[u], dl2, NBK_FMA(vy[u], dl1, vx[u] * dl0));
-                    if (pr > best) { best = pr; bi = k + u; }
-                }
-            }
-            for (; k < hn; ++k) {
-                const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
-                if (pr > best) { best = pr; bi = k; }
-            }
-            const double* v = hv + 3 * bi;
-            const double v0 = v[0], v1 = v[1], v2 = v[2];
+            double v0, v1, v2;
+            // k_narrow* stage the scene's hull vertices in LDS and leave the hull's LDS byte address in `rad` (unused by hulls, 0
+            // everywhere else): the same loop through ds_read instead of per-lane global loads
+            if (s.rad > 0.0) hull_first_max(reinterpret_cast<LdsDoubleP>((unsigned)s.rad), hn, dl0, dl1, dl2, v0, v1, v2);
+            else hull_first_max(hull_hv(s), hn, dl0, dl1, dl2, v0, v1, v2);
             copy3(s.c, o);
             axpy3(v0, s.ax[0], o, o);
             axpy3(v1, s.ax[1], o, o);
@@ -212,15 +231,9 @@ NBK_DEV double core_halfwidth(const Core& s, const double* n) {
 NBK_DEV void core_extents(const Core& s, const double* n, double& neg, double& pos) {
     if (s.kind != K_HULL) { const double hw = core_halfwidth(s, n); neg = hw; pos = hw; return; }
     const double dl0 = dot3(n, s.ax[0]), dl1 = dot3(n, s.ax[1]), dl2 = dot3(n, s.ax[2]);
-    const double* hv = hull_hv(s);
     const int hn = hull_hn(s);
-    double hi = -NBK_INF, lo = NBK_INF;
-    for (int k = 0; k < hn; ++k) {
-        const double pr = NBK_FMA(hv[3 * k + 2], dl2, NBK_FMA(hv[3 * k + 1], dl1, hv[3 * k] * dl0));
-        if (pr > hi) hi = pr;
-        if (pr < lo) lo = pr;
-    }
-    pos = hi; neg = -lo;
+    if (s.rad > 0.0) hull_min_max(reinterpret_cast<LdsDoubleP>((unsigned)s.rad), hn, dl0, dl1, dl2, neg, pos);      // (vertices staged in LDS)
+    else hull_min_max(hull_hv(s), hn, dl0, dl1, dl2, neg, pos);
 }
 
 // ---- GJK ---------------------------------------------------------------------------------------
