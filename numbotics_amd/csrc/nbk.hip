@@ -2456,10 +2456,22 @@ NBK_DEV void narrow_body(const DevModel& m, const EdgeSrc& es, const double* __r
             if (live && !(NBK_DBG(m) & 32)) {
                 build_core(m, ra, TA, A);
                 build_core(m, rb, TB, Bc);
-                if (hull_staged) {       // the support routine reads the vertices at the LDS address in `rad`; everything else keeps HullRef.hv
+                if (hull_staged) {
+                    // HullRef.hv is redirected to the LDS copy (a flat address: the support routine's loop stays the one every kernel
+                    // shares); the extent routine, which the overlap-depth estimate calls per face, gets the LDS address proper in `rad`
+                    // (unused by hulls) and reads with ds_read.  The same split for the support routine costs the distance kernels,
+                    // which never stage, 5 % (a second loop behind a run-time branch): measured, not kept.
                     const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) double*)hull_lds);
-                    if (A.kind == K_HULL) A.rad = (double)(lds0 + 8u * (unsigned)(hull_hv(A) - m.hull_blob));
-                    if (Bc.kind == K_HULL) Bc.rad = (double)(lds0 + 8u * (unsigned)(hull_hv(Bc) - m.hull_blob));
+                    if (A.kind == K_HULL) {
+                        const long off = hull_hv(A) - m.hull_blob;
+                        A.rad = (double)(lds0 + 8u * (unsigned)off);
+                        A.h[0] = __builtin_bit_cast(double, reinterpret_cast<unsigned long long>(hull_lds + off));
+                    }
+                    if (Bc.kind == K_HULL) {
+                        const long off = hull_hv(Bc) - m.hull_blob;
+                        Bc.rad = (double)(lds0 + 8u * (unsigned)off);
+                        Bc.h[0] = __builtin_bit_cast(double, reinterpret_cast<unsigned long long>(hull_lds + off));
+                    }
                 }
                 if (prof) { double acc = 0.0; for (int e = 0; e < 3; ++e) acc += A.c[e] + Bc.c[e] + A.ax[0][e] + A.ax[2][e] + Bc.ax[0][e] + Bc.ax[2][e] + A.h[e] + Bc.h[e]; if (acc == 12345.678) mark_hit(b, mask_bits, mask_bytes); }
                 NBK_STAMP(4);

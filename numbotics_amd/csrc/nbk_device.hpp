@@ -190,10 +190,7 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
             const double dl0 = dot3(d, s.ax[0]), dl1 = dot3(d, s.ax[1]), dl2 = dot3(d, s.ax[2]);
             const int hn = hull_hn(s);
             double v0, v1, v2;
-            // k_narrow* stage the scene's hull vertices in LDS and leave the hull's LDS byte address in `rad` (unused by hulls, 0
-            // everywhere else): the same loop through ds_read instead of per-lane global loads
-            if (s.rad > 0.0) hull_first_max(reinterpret_cast<LdsDoubleP>((unsigned)s.rad), hn, dl0, dl1, dl2, v0, v1, v2);
-            else hull_first_max(hull_hv(s), hn, dl0, dl1, dl2, v0, v1, v2);
+            hull_first_max(hull_hv(s), hn, dl0, dl1, dl2, v0, v1, v2);       // (k_narrow*: hv may be a flat address of the LDS copy)
             copy3(s.c, o);
             axpy3(v0, s.ax[0], o, o);
             axpy3(v1, s.ax[1], o, o);
@@ -228,11 +225,16 @@ NBK_DEV double core_halfwidth(const Core& s, const double* n) {
 
 // extents of a core along unit direction n about its centre: the core spans [-neg, +pos].  Symmetric kinds: both are the
 // half width; hull: pos = max_k dl.v_k, neg = -min_k dl.v_k with dl = n in local coordinates.
+// LDSV: the caller may hold cores whose hull vertices k_narrow* staged in LDS (their LDS byte address in `rad`, unused by hulls and 0
+// everywhere else): read them with ds_read.  Only the overlap-depth CALL of the predicate instantiates it (overlap_depth_copy below), so
+// the kernels that never stage -- the distance kernels above all -- keep one loop and no branch (with the branch in the shared
+// routine they lost 6 % on the mesh scene).
+template <bool LDSV = false>
 NBK_DEV void core_extents(const Core& s, const double* n, double& neg, double& pos) {
     if (s.kind != K_HULL) { const double hw = core_halfwidth(s, n); neg = hw; pos = hw; return; }
     const double dl0 = dot3(n, s.ax[0]), dl1 = dot3(n, s.ax[1]), dl2 = dot3(n, s.ax[2]);
     const int hn = hull_hn(s);
-    if (s.rad > 0.0) hull_min_max(reinterpret_cast<LdsDoubleP>((unsigned)s.rad), hn, dl0, dl1, dl2, neg, pos);      // (vertices staged in LDS)
+    if (LDSV && s.rad > 0.0) hull_min_max(reinterpret_cast<LdsDoubleP>((unsigned)s.rad), hn, dl0, dl1, dl2, neg, pos);
     else hull_min_max(hull_hv(s), hn, dl0, dl1, dl2, neg, pos);
 }
 
@@ -507,6 +509,7 @@ NBK_DEV bool gjk_cores(const Core& A, const Core& Bc, double* vout, double* pa, 
     return false;
 }
 
+template <bool LDSV = false>
 NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
 // the predicate's use of it (negative tc, penetrating cores) goes through a real call on COPIES of the cores: inlined into the
 // GJK loop its fifteen-axis family drove k_narrow / k_narrow_pred to 600+ spilled VGPRs once the cores lived in registers
@@ -580,6 +583,7 @@ NBK_DEV int gjk_pred_step(GjkPred& g, const Core& A, const Core& Bc, double tc) 
     return (nbk_sqrt(dot3(g.v, g.v)) < tc) ? 2 : 1;
 }
 
+template <bool LDSV>
 NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
 
 NBK_DEV bool gjk_collides(const Core& A, const Core& Bc, double tc) {
@@ -719,6 +723,7 @@ NBK_DEV int gjk_intersect_inflated(const Core& A, const Core& Bc, double tc) {
 }
 
 // ---- overlap depth over the candidate axis family ---------------------------------------------
+template <bool LDSV = false>
 NBK_DEV void try_axis(const Core& A, const Core& Bc, const double* delta, const double* n_in, double& best, double* bn) {
     const double nn = dot3(n_in, n_in);
     if (!(nn > 1e-24)) return;
@@ -728,8 +733,8 @@ NBK_DEV void try_axis(const Core& A, const Core& Bc, const double* delta, const 
     if (A.kind == K_HULL || Bc.kind == K_HULL) {
         // not centrally symmetric: pushing A along +n separates after tp = (aN + bP) - proj, along -n after tm = (aP + bN) + proj
         double aN, aP, bN, bP;
-        core_extents(A, n, aN, aP);
-        core_extents(Bc, n, bN, bP);
+        core_extents<LDSV>(A, n, aN, aP);
+        core_extents<LDSV>(Bc, n, bN, bP);
         const double tp = (aN + bP) - proj, tm = (aP + bN) + proj;
         const double ov = tp <= tm ? tp : tm;
         if (ov < best) {
@@ -761,6 +766,7 @@ NBK_DEV int core_naxes(const Core& s) { return s.kind == K_BOX ? 3 : ((s.kind ==
 // axis i of the family of core s: box -> ax[i]; seg/cyl -> ax[2]
 NBK_DEV const double* core_axis(const Core& s, int i) { return s.kind == K_BOX ? s.ax[i] : s.ax[2]; }
 
+template <bool LDSV>
 NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
     double delta[3];
     sub3(A.c, Bc.c, delta);
@@ -768,9 +774,9 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
     normal[0] = 1.0; normal[1] = 0.0; normal[2] = 0.0;
     const int na = core_naxes(A), nb = core_naxes(Bc);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) if (i < na) try_axis(A, Bc, delta, core_axis(A, i), best, normal);
+    for (int i = 0; i < 3; ++i) if (i < na) try_axis<LDSV>(A, Bc, delta, core_axis(A, i), best, normal);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) if (j < nb) try_axis(A, Bc, delta, core_axis(Bc, j), best, normal);
+    for (int j = 0; j < 3; ++j) if (j < nb) try_axis<LDSV>(A, Bc, delta, core_axis(Bc, j), best, normal);
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -778,21 +784,23 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
             if (i < na && j < nb) {
                 double cr[3];
                 cross3(core_axis(A, i), core_axis(Bc, j), cr);
-                try_axis(A, Bc, delta, cr, best, normal);
+                try_axis<LDSV>(A, Bc, delta, cr, best, normal);
             }
     // face normals of hull cores (exact for a point inside a hull, an upper bound otherwise: no edge-edge axes)
-    if (A.kind == K_HULL) for (int f = 0, nf = hull_hf(A); f < nf; ++f) { double fn[3]; hull_face_normal(A, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
-    if (Bc.kind == K_HULL) for (int f = 0, nf = hull_hf(Bc); f < nf; ++f) { double fn[3]; hull_face_normal(Bc, f, fn); try_axis(A, Bc, delta, fn, best, normal); }
-    if (A.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A.ax[2]), A.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
-    if (Bc.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc.ax[2]), Bc.ax[2], delta, r); try_axis(A, Bc, delta, r, best, normal); }
-    try_axis(A, Bc, delta, delta, best, normal);
+    if (A.kind == K_HULL) for (int f = 0, nf = hull_hf(A); f < nf; ++f) { double fn[3]; hull_face_normal(A, f, fn); try_axis<LDSV>(A, Bc, delta, fn, best, normal); }
+    if (Bc.kind == K_HULL) for (int f = 0, nf = hull_hf(Bc); f < nf; ++f) { double fn[3]; hull_face_normal(Bc, f, fn); try_axis<LDSV>(A, Bc, delta, fn, best, normal); }
+    if (A.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, A.ax[2]), A.ax[2], delta, r); try_axis<LDSV>(A, Bc, delta, r, best, normal); }
+    if (Bc.kind == K_CYL) { double r[3]; axpy3(-dot3(delta, Bc.ax[2]), Bc.ax[2], delta, r); try_axis<LDSV>(A, Bc, delta, r, best, normal); }
+    try_axis<LDSV>(A, Bc, delta, delta, best, normal);
     if (best == NBK_INF) best = 0.0;
     return best;
 }
 
 __device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc) {
     double nrm[3];
-    return overlap_depth(A, Bc, nrm);
+    if (A.rad > 0.0 && A.kind == K_HULL) return overlap_depth<true>(A, Bc, nrm);
+    if (Bc.rad > 0.0 && Bc.kind == K_HULL) return overlap_depth<true>(A, Bc, nrm);
+    return overlap_depth<false>(A, Bc, nrm);
 }
 
 // ---- closed forms for point / segment cores ---------------------------------------------------
