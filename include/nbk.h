@@ -17,7 +17,11 @@
  *     stream's FIRST call (and regrown when a later batch needs more): such a call allocates and may
  *     wait for that stream's earlier work.  Captured before the scratch exists they return
  *     NBK_ERR_UNSUPPORTED (run the call once outside the capture, or use nbk_validity_batch_ws, whose
- *     scratch is the caller's); captured after, they are self-contained graph nodes.  The *_host
+ *     scratch is the caller's); captured after, they are self-contained graph nodes: each replay
+ *     prepares its own tables and clears its own counters in the stream's scratch, and direct calls
+ *     made on that stream afterwards (in any order with the replays) do the same -- they no longer
+ *     reuse tables between calls.  A graph holds the scratch's address: do not replay it after a
+ *     direct call on the same stream with a LARGER batch has regrown the scratch (re-capture).  The *_host
  *     conveniences synchronise by definition.  Batches of 2^21 configurations or more (and edge batches of that many samples)
  *     run every other 2^20-configuration tile on a second, library-owned stream forked from and joined to `stream` with
  *     events -- the call still begins after, and completes before, its neighbours in `stream`'s order;
@@ -93,7 +97,10 @@ typedef struct {
     const double *hull_verts;        /* [NV][3] */
     const int32_t *hull_face_begin;  /* [H+1]; a hull may have no planes (flat point set): distances stay exact, the
                                         penetration depth then falls back to the other shape's axes and the centre line */
-    const double *hull_planes;       /* [NF][4] unit outward normal n and offset d: inside n.x <= d */
+    const double *hull_planes;       /* [NF][4] unit outward normal n and offset d: inside n.x <= d.  nbk_model_create checks
+                                        ||n|^2 - 1| <= 1e-9 and n.v <= d (+1e-9 relative) for every vertex of the hull and
+                                        returns NBK_ERR_INVALID otherwise: the broadphase certifies collisions from the ball
+                                        these planes inscribe */
 } nbk_model_desc;
 
 typedef struct nbk_model nbk_model;

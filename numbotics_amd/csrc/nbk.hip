@@ -126,6 +126,10 @@ struct StreamWs {
     std::mutex mu;                  // two host threads driving one stream
     void* ws; size_t ws_bytes;
     bool ready; double thr; unsigned epoch;
+    bool captured;                  // a call on this stream has been captured into a hipGraph: its nodes reuse this workspace (counter
+                                    // set 0, the tables for THEIR threshold) whenever the graph is replayed, behind the host's back, so
+                                    // direct calls on this stream never trust `ready` again -- each prepares its tables and clears both
+                                    // counter sets itself (one more 5 us launch per call)
     void* ews; size_t ews_bytes;
     long long ecap_edges; unsigned long long ecap_samples;
     unsigned long long* stats;      // [4] pinned + mapped: samples needed by the last finished edge call, edges served by the overflow kernel
@@ -3109,6 +3113,30 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         if (h == 0 && (d->hull_vert_begin[0] != 0 || d->hull_face_begin[0] != 0)) return NBK_ERR_INVALID;
     }
     if (H > 0 && d->hull_face_begin[H] > 0 && d->hull_planes == nullptr) return NBK_ERR_INVALID;
+    // face planes: unit outward normals that bound the vertex set (n.v <= d for every vertex).  The float32 broadphase certifies
+    // hits from the ball the planes inscribe and the overlap depth walks them: planes that are not what nbk.h asks for would
+    // produce verdicts neither the narrowphase nor the oracle ever re-examines.
+    for (int h = 0; h < H; ++h) {
+        const double* v = d->hull_verts + 3 * (size_t)d->hull_vert_begin[h];
+        const int nv = d->hull_vert_begin[h + 1] - d->hull_vert_begin[h];
+        double vmax = 0.0;
+        for (int i = 0; i < 3 * nv; ++i) { if (!(fabs(v[i]) <= 1e300)) return NBK_ERR_INVALID; vmax = std::max(vmax, fabs(v[i])); }
+        for (int f = d->hull_face_begin[h]; f < d->hull_face_begin[h + 1]; ++f) {
+            const double* pl = d->hull_planes + 4 * (size_t)f;
+            const double n2 = pl[0] * pl[0] + pl[1] * pl[1] + pl[2] * pl[2];
+            if (!(fabs(n2 - 1.0) <= 1e-9) || !(fabs(pl[3]) <= 1e300)) {
+                snprintf(g_err, sizeof(g_err), "hull %d, plane %d: the normal must have unit length (|n|^2 = %.17g)", h, f - d->hull_face_begin[h], n2);
+                return NBK_ERR_INVALID;
+            }
+            const double tol = 1e-9 * (1.0 + fabs(pl[3]) + vmax);
+            for (int i = 0; i < nv; ++i)
+                if (pl[0] * v[3 * i] + pl[1] * v[3 * i + 1] + pl[2] * v[3 * i + 2] > pl[3] + tol) {
+                    snprintf(g_err, sizeof(g_err), "hull %d, plane %d does not bound vertex %d (n.v - d = %.3g)", h, f - d->hull_face_begin[h], i,
+                             pl[0] * v[3 * i] + pl[1] * v[3 * i + 1] + pl[2] * v[3 * i + 2] - pl[3]);
+                    return NBK_ERR_INVALID;
+                }
+        }
+    }
     auto hull_ok = [&](double idx) { return idx >= 0.0 && idx < (double)H && idx == (double)(int)idx; };
     for (int k = 0; k < J; ++k) {
         if (d->joint_parent[k] >= k || d->joint_parent[k] < -1) return NBK_ERR_INVALID;   // parents first
@@ -3911,7 +3939,7 @@ static StreamWs* stream_ws(nbk_model* mm, hipStream_t st) {
     for (StreamWs* w : mm->wss) if (w->stream == st) return w;
     if (mm->wss.size() >= 64) return nullptr;
     StreamWs* w = new StreamWs();
-    w->stream = st; w->ws = nullptr; w->ws_bytes = 0; w->ready = false; w->thr = 0.0; w->epoch = 0;
+    w->stream = st; w->ws = nullptr; w->ws_bytes = 0; w->ready = false; w->thr = 0.0; w->epoch = 0; w->captured = false;
     w->ews = nullptr; w->ews_bytes = 0; w->ecap_edges = 0; w->ecap_samples = 0; w->stats = nullptr; w->stats_dev = nullptr;
     w->aux_stream = nullptr; w->ev_fork = nullptr; w->ev_join = nullptr; w->aux = nullptr;
     mm->wss.push_back(w);
@@ -3933,7 +3961,15 @@ static int32_t grow_scratch(hipStream_t st, void*& buf, size_t& have, size_t nee
 // queue fits the workspace.  `iw`: the workspace is this stream's own set and keeps state between calls (tables, counter epoch);
 // nullptr: caller-owned workspace, or a call being captured into a graph -- self-contained: every call prepares its tables
 // and clears its counters itself.
-#define PIPE_TILE (g_opt.pipe_tile > 0 ? (int64_t)g_opt.pipe_tile : (int64_t(1) << 20))      // tile size of pipelined batches (NBK_PIPE_TILE)
+// tile size of pipelined batches (NBK_PIPE_TILE): whole 64-configuration blocks (tiles on the two streams must not share a mask word
+// or a block), at least one block per sub-queue; anything else is rounded / clamped here, so no value of the switch changes a result
+static inline int64_t pipe_tile_configs() {
+    int64_t t = g_opt.pipe_tile > 0 ? (int64_t)g_opt.pipe_tile : (int64_t(1) << 20);
+    t &= ~int64_t(WAVE - 1);
+    const int64_t lo = (int64_t)NSUB * WAVE;
+    return t < lo ? lo : t;
+}
+#define PIPE_TILE pipe_tile_configs()
 static inline bool pipelined(const nbk_model* m, int64_t B) { return g_opt.pipeline_tiles != 0 && m->parked_ok && B >= 2 * PIPE_TILE; }
 static inline int64_t call_tile(const nbk_model* m, const PairCounts& pc, int64_t B, bool pipe) {
     const int64_t t = tile_configs(m, pc, B);
@@ -3990,7 +4026,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16;
         unsigned long long* count_next = nullptr;
         if (use_reg && f32) {
-            if (internal && iw->ready && iw->thr == threshold) {
+            if (internal && iw->ready && !iw->captured && iw->thr == threshold) {
                 // tables are in place and the previous call's narrowphase cleared this call's counter set: no launch
                 count = count_set0 + (size_t)(iw->epoch & 1u) * NSUB * CNT_STRIDE;
                 count_next = count_set0 + (size_t)((iw->epoch + 1u) & 1u) * NSUB * CNT_STRIDE;
@@ -4135,7 +4171,7 @@ int32_t nbk_validity_batch(const nbk_model* m, const double* q, int64_t B, doubl
     }
     // a captured call must be self-contained (it is replayed out of order with the host-side state): prepare + clear inside
     // the graph, and the next direct call starts from scratch as well
-    if (capturing) w->ready = false;
+    if (capturing) { w->ready = false; w->captured = true; }
     if (pipe) { const int32_t rc = pipe_setup(const_cast<nbk_model*>(m), m, pc, w, B, st); if (rc != NBK_OK) return rc; }
     return launch_two_kernel(m, pc, NO_EDGES, q, B, threshold, mask_bits, mask_bytes, w->ws, st, capturing ? nullptr : w, pipe);
 }
@@ -4305,7 +4341,7 @@ int32_t nbk_edge_validity_batch(const nbk_model* m, const double* starts, const 
     hipLaunchKernelGGL(k_edge_expand, dim3((unsigned)E), dim3(WAVE), 0, st, offs, E, map, cap, ovf);
     NBK_HIP(hipGetLastError());
     EdgeSrc es{starts, goals, plan, map, offs + E, 0, nullptr};
-    if (capturing) w->ready = false;
+    if (capturing) { w->ready = false; w->captured = true; }
     const bool pipe = pipelined(m, (int64_t)cap) && !capturing;
     if (pipe) { const int32_t rp = pipe_setup(const_cast<nbk_model*>(m), m, pc, w, (int64_t)cap, st); if (rp != NBK_OK) return rp; }
     const int32_t rc = launch_two_kernel(m, pc, es, nullptr, (int64_t)cap, threshold, words, nullptr, w->ws, st, capturing ? nullptr : w, pipe);

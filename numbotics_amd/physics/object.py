@@ -150,8 +150,9 @@ class Plane(PhysicsObject):
 
 class Mesh(PhysicsObject):
     """Mesh obstacle (reference: physics/object.py:425-447).  Shape kwargs as upstream: ``mesh_scale``, ``offset``,
-    ``auto_center``, ``convex_decomposition``.  Collision geometry = one convex hull per object of the file (what Bullet's
-    GEOM_MESH is without the concave flag; numbotics_amd/utils/mesh.py); the file is read when the scene is compiled."""
+    ``auto_center``, ``convex_decomposition``.  Collision geometry = ONE convex hull of the whole file (trimesh merges the
+    file's objects before the reference exports it for Bullet's GEOM_MESH), or with ``convex_decomposition=True`` one hull per
+    object of the file (numbotics_amd/utils/mesh.py); the file is read when the scene is compiled."""
     def __init__(self, mass: float, filename: str, static: bool = False, **kwargs):
         self._filename = filename
         _static_mass_warning('Mesh', mass, static)

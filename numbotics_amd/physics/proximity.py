@@ -38,7 +38,7 @@ def _static_shapes(entity):
     raise ValueError(f"cannot measure distances of {type(entity).__name__}")
 
 
-def body_distances(subject, target, max_distance: float = np.inf, bullet_margins: bool = False):
+def body_distances(subject, target, max_distance: float = np.inf, bullet_margins: bool = True):
     """``list[Proximity]`` between every shape of ``subject`` and every shape of ``target`` with distance <= max_distance."""
     from numbotics_amd.robots.model import (KinematicModel, SceneModel, HullTable, _shape_records, _T34, SH_PLANE)
     from numbotics_amd.engine import DeviceModel

@@ -31,10 +31,13 @@ def _is_tensor(x):
 
 class Arm(Robot):
 
-    def __init__(self, chain, weld_filter: bool = False, compound: bool = True, bullet_margins: bool = False):
-        """``bullet_margins`` (additive, default False = sharp shapes): give every box / cylinder / mesh hull that has no explicit
-        ``collision_margin`` the margin Bullet itself applies (robots/model.py ``bullet_margin``) -- the mode to expect closest to
-        the reference's PyBullet distances; can be switched later through the ``bullet_margins`` property."""
+    def __init__(self, chain, weld_filter: bool = False, compound: bool = True, bullet_margins: bool = True):
+        """``bullet_margins`` (additive, default True): every box / cylinder / mesh hull that has no explicit ``collision_margin``
+        gets the margin Bullet itself applies to the shapes ``pybullet.createCollisionShape`` builds for the reference
+        (numbotics/utils/shape.py:60-109; robots/model.py ``bullet_margin``: boxes / cylinders are rounded by
+        min(0.04, a tenth of the smallest half extent), hulls inflated by 0.001) -- the restatement closest to the reference's
+        ``getClosestPoints`` answers.  ``False`` = the sharp analytic shapes (margin 0); can be switched later through the
+        ``bullet_margins`` property."""
         super().__init__(chain)
         self._weld_filter = weld_filter
         self._compound = compound

@@ -190,8 +190,9 @@ def _margin(cs, bullet_margins: bool) -> float:
 
 
 def _shape_records(cs, owner_pose_local: np.ndarray, hulls: HullTable, bullet_margins: bool = False):
-    """[(type, 3x4 pose in the owner frame, params[4])] for one CollisionShape: one record, except for a MESH, which
-    yields one convex hull per object of its file (numbotics/utils/shape.py:81-94 -> Bullet GEOM_MESH)."""
+    """[(type, 3x4 pose in the owner frame, params[4])] for one CollisionShape: one record, except for a MESH with
+    ``convex_decomposition=True``, which yields one convex hull per object of its file (numbotics/utils/shape.py:81-94 -> Bullet
+    GEOM_MESH; without the flag a mesh is one hull of all its vertices, utils/mesh.py:mesh_hulls)."""
     if cs.shape == Shape.MESH:
         from numbotics_amd.utils.mesh import mesh_hulls
         info = cs._shape_info
@@ -307,7 +308,7 @@ class SceneModel:
         return subj, self.objects[self.wshape_obj[b - self.n_rshapes]]
 
 
-def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True, bullet_margins: bool = False) -> SceneModel:
+def compile_scene(chain, kin: KinematicModel, pairs, compound: bool = True, bullet_margins: bool = True) -> SceneModel:
     """``pairs``: iterable of (Link, Link | PhysicsObject) as produced by ``Arm.collision_pairs()``.
     ``bullet_margins``: shapes without an explicit ``collision_margin`` get the margin Bullet would give them
     (``bullet_margin`` above) instead of 0 -- the setting closest to what the reference's ``getClosestPoints`` measures."""

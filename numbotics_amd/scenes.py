@@ -5,9 +5,11 @@ c2 : arm + one Cube(half_extent=0.4) at [1.0, 0.0, 0.2] (reference README.md:96)
      rule minus the hand removals of numbotics/tests/_test_rrt.py:38-61.
 c3 : arm + 8 Cube(half_extent=0.25) on a ring of radius 0.9 m, heights alternating 0.25 / 0.75 m, angles
      k*45 deg (build-defined: the reference has no 8-cube scene).
-c2m: c2 with the arm's collision primitives replaced by meshes (models/kinova_mesh.urdf: one convex hull per mesh object,
-     the bracelet link a two-object compound file).
-c5m: the mesh arm among mesh obstacles -- a rock (one hull), a table (compound: five objects in one OBJ), a wedge (binary
+c2m: c2 with the arm's collision primitives replaced by meshes (models/kinova_mesh.urdf: one convex hull per mesh file,
+     the bracelet link a compound of two <collision> elements).
+c5m: the mesh arm among mesh obstacles -- a rock (one hull), a table (compound: the five objects of one OBJ loaded with
+     convex_decomposition=True, i.e. the file taken as its own decomposition; without the flag it would be ONE hull, as in
+     the reference, whose trimesh round trip merges the objects of a file), a wedge (binary
      STL, scaled and rotated through the shape kwargs) and one Cube: BASELINE config 5's "compound-mesh collision shapes"
      (build-defined layout: the reference ships no mesh scene, numbotics/tests/_test_manual.py:41 loads a single mesh body).
 The Kinova URDF is this build's own asset (numbotics_amd/models/kinova_cyl.urdf).
@@ -40,7 +42,7 @@ def apply_rrt_script_removals(arm):
         logger.VERBOSE = verbose
 
 
-def build_scene(name: str = "c2", urdf: str = None, bullet_margins: bool = False):
+def build_scene(name: str = "c2", urdf: str = None, bullet_margins: bool = True):
     """-> (arm, chain, obstacles).  Keep the returned obstacles alive: the world holds weak references."""
     from numbotics_amd.physics import GraphChain, Cube, Mesh
     from numbotics_amd.robots import Arm
@@ -57,7 +59,7 @@ def build_scene(name: str = "c2", urdf: str = None, bullet_margins: bool = False
     elif name == "c5m":
         from numbotics_amd.math import rpy_matrix, trans_mat
         obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "rock.obj"), position=np.array([0.55, 0.25, 0.45])))
-        obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "table.obj"), position=np.array([0.0, -0.75, 0.0])))
+        obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "table.obj"), position=np.array([0.0, -0.75, 0.0]), convex_decomposition=True))
         obstacles.append(Mesh(0.0, os.path.join(MESH_DIR, "wedge.stl"), mesh_scale=np.array([1.5, 1.5, 1.2]),
                               offset=trans_mat(pos=np.array([-0.1, -0.1, 0.0]), orn=rpy_matrix(np.array([0.0, 0.0, 0.6]))),
                               position=np.array([-0.6, 0.35, 0.0])))

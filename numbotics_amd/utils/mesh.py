@@ -6,15 +6,24 @@ hands that file to ``pybullet.createCollisionShape(GEOM_MESH, fileName=...)``.  
 the reference never sets) Bullet turns every OBJ object of that file into one convex hull and the body into the compound
 of those hulls.  So what the collision path sees of a mesh is: a list of convex hulls.
 
+WHICH objects the exported file has is decided by trimesh, not by the source file: ``trimesh.load`` merges the objects /
+groups of a single-material OBJ (its loader's defaults ``split_object=False, group_material=True``) and the solids of an
+STL into ONE ``Trimesh``, whose export is one object -- Bullet then builds ONE hull of the whole vertex set, however many
+``o`` / ``g`` statements the source had.  Only ``convex_decomposition=True`` produces a multi-object export (the
+``trimesh.Scene`` of the V-HACD parts).  (A multi-MATERIAL OBJ loads as a ``Scene``, on which the reference's
+``center_mass`` / ``convex_decomposition`` calls do not exist; such files are read here like single-material ones.)
+
 This module produces exactly that list -- no temporary file, no PyBullet:
 
-* own readers for Wavefront OBJ (``v`` / ``f`` / ``o`` / ``g``; one part per object or group, as tinyobjloader splits
-  them) and STL (ASCII and binary; one part per ``solid``); trimesh / vhacdx are third-party and absent here;
+* own readers for Wavefront OBJ (``v`` / ``f`` / ``o`` / ``g``; one part per object or group) and STL (ASCII and binary;
+  one part per ``solid``); trimesh / vhacdx are third-party and absent here;
 * ``load_mesh`` applies the reference's transform sequence (auto-centre, scale, offset) to the vertices;
-* ``convex_hull`` (scipy.spatial.ConvexHull = Qhull) reduces a part to its hull vertices and merged face planes.
+* ``mesh_hulls``: ``convex_decomposition=False`` (the default) -> ONE hull of all the file's vertices;
+  ``convex_decomposition=True`` -> one hull per object of the file;
+* ``convex_hull`` (scipy.spatial.ConvexHull = Qhull) reduces a vertex set to its hull vertices and merged face planes.
 
 ``convex_decomposition=True`` cannot be reproduced (V-HACD is not available): a file that already holds several objects
-is taken as the decomposition (one hull per object -- what Bullet would build from the reference's exported scene);
+is taken as its own decomposition (one hull per object -- what Bullet would build from an exported scene with those parts);
 a single-object file raises ``NotImplementedError`` naming the missing dependency.
 
 Parity: trimesh's loaders and ``center_mass`` are third-party and absent, so this reader is pinned only by its own
@@ -252,8 +261,14 @@ def convex_hull(points) -> ConvexPart:
 
 
 def mesh_hulls(filename: str, **kwargs):
-    """[ConvexPart] of a MESH shape: one hull per object of the (transformed) file."""
-    return [convex_hull(p.vertices) for p in load_mesh(filename, **kwargs)]
+    """[ConvexPart] of a MESH shape.  ``convex_decomposition=False``: one hull of every vertex of the (transformed) file -- the
+    reference hands Bullet trimesh's re-export of the loaded file, in which the objects of the source are merged into one
+    (module docstring).  ``convex_decomposition=True``: one hull per object of the file (the file is its own decomposition).
+    Third-party behaviour (trimesh, Bullet) restated from their documentation: parity unpinned."""
+    parts = load_mesh(filename, **kwargs)
+    if kwargs.get('convex_decomposition', False):
+        return [convex_hull(p.vertices) for p in parts]
+    return [convex_hull(np.concatenate([p.vertices for p in parts], axis=0))]
 
 
 # ---- writers (tests, tools, assets) ---------------------------------------------------------------------------------------

@@ -107,11 +107,15 @@ def test_jacobian_bitwise_and_golden(kinova, g3, golden_meta, torch_cuda):
     assert np.array_equal(arm.jacobian(q[:4], "base_link"), np.zeros((4, 6, 7)))  # arm.py:455-457
 
 
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("scene", ["c1", "c2", "c3"])
-def test_validity_mask_bitwise(fresh_world, scene, torch_cuda):
-    """c1: the arm alone (self-collision pairs only, no world shape at all), c2 / c3: BASELINE configs 2 and 3."""
-    arm, chain, obs = build_scene(scene)
+def test_validity_mask_bitwise(fresh_world, scene, margins, torch_cuda):
+    """c1: the arm alone (self-collision pairs only, no world shape at all), c2 / c3: BASELINE configs 2 and 3; in the default
+    mode (Bullet's shape margins, ``Arm(chain)``) and with sharp shapes (``bullet_margins=False``)."""
+    arm, chain, obs = build_scene(scene, bullet_margins=margins)
+    assert arm.bullet_margins == margins
     sm = arm.scene_model()
+    assert ((sm.rshape_param[:, 3] > 0).sum() >= 9) == margins
     assert (sm.n_wshapes == 0) == (scene == "c1")
     orc = Oracle(sm)
     q = sample_q(chain, 20000, seed=2)
@@ -169,9 +173,10 @@ def ref_first(orc, q0):
     return orc.validity(q0.reshape(1, -1))[0]
 
 
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("scene", ["c2", "c3"])
-def test_distances_bitwise(fresh_world, scene, torch_cuda):
-    arm, chain, obs = build_scene(scene)
+def test_distances_bitwise(fresh_world, scene, margins, torch_cuda):
+    arm, chain, obs = build_scene(scene, bullet_margins=margins)
     sm = arm.scene_model()
     orc = Oracle(sm)
     q = sample_q(chain, 3000, seed=3)
@@ -242,10 +247,11 @@ def test_one_wave_per_edge_kernel_still_agrees(fresh_world, torch_cuda):
             assert_bitwise(end, endr, "k_edges end states")
 
 
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("mode", ["connect", "steer"])
-def test_edge_validity(fresh_world, mode, torch_cuda):
+def test_edge_validity(fresh_world, mode, margins, torch_cuda):
     from numbotics_amd.planning.sampling_based import ConnectorParams, DiscreteConnector
-    arm, chain, obs = build_scene("c3")
+    arm, chain, obs = build_scene("c3", bullet_margins=margins)
     orc = Oracle(arm.scene_model())
     rng = np.random.default_rng(6)
     lim = chain.joint_limits
@@ -294,10 +300,11 @@ def test_edge_matches_per_sample_walk(fresh_world, torch_cuda):
     assert n_none > 0
 
 
-def test_full_size_properties(fresh_world, torch_cuda):
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
+def test_full_size_properties(fresh_world, margins, torch_cuda):
     """BASELINE config 2 at full size (1e6 q): size-independent properties + oracle on a slice."""
     torch = torch_cuda
-    arm, chain, obs = build_scene("c2")
+    arm, chain, obs = build_scene("c2", bullet_margins=margins)
     orc = Oracle(arm.scene_model())
     B = 1_000_000
     q = sample_q(chain, B, seed=1)
@@ -711,11 +718,12 @@ def test_random_mechanisms_and_scenes(fresh_world, seed, torch_cuda, tmp_path):
     assert len(obs) >= 1
 
 
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("scene", ["c2", "c3"])
-def test_contact_transitions_are_resolved_exactly(fresh_world, scene, torch_cuda):
+def test_contact_transitions_are_resolved_exactly(fresh_world, scene, margins, torch_cuda):
     """The float32 broadphase may only cull what is certainly free: sweep one joint in steps of 1e-10 rad across
     collision / free transitions found by bisection on the oracle, and ask for the same mask bit for bit."""
-    arm, chain, obs = build_scene(scene)
+    arm, chain, obs = build_scene(scene, bullet_margins=margins)
     orc = Oracle(arm.scene_model())
     base = sample_q(chain, 3000, seed=77)
     m0 = orc.validity(base, 0.0, nthreads=8)
@@ -1280,6 +1288,63 @@ def test_internal_workspace_calls_are_capturable_once_allocated(fresh_world, tor
     assert np.array_equal(words.cpu().numpy(), dev.validity(q, 0.0, packed=True).cpu().numpy())
 
 
+def test_graph_replays_interleaved_with_direct_calls(fresh_world, torch_cuda):
+    """capture, direct, direct, replay, direct -- with another threshold and a SMALLER batch in the direct calls.  A replayed graph
+    rewrites the stream's float32 tables for its own threshold and leaves counter set 0 non-empty behind the host's back; direct
+    calls on a stream that has captured therefore never reuse cached tables / counter sets (StreamWs::captured).  Every mask
+    against the oracle."""
+    import ctypes as C
+    torch = torch_cuda
+    from numbotics_amd import _lib
+    arm, chain, obs = build_scene("c3")
+    orc = Oracle(arm.scene_model())
+    _, dev = arm._scene_device()
+    lib = _lib.load()
+    B, Bs = 40000, 9000
+    q = torch.from_numpy(sample_q(chain, B, seed=31)).cuda()
+    qs = torch.from_numpy(sample_q(chain, Bs, seed=32)).cuda()
+    words = torch.zeros(((B + 63) // 64,), dtype=torch.int64, device="cuda")
+    words_s = torch.zeros(((Bs + 63) // 64,), dtype=torch.int64, device="cuda")
+    ref = {thr: np.packbits(orc.validity(q.cpu().numpy(), thr, nthreads=8), bitorder="little") for thr in (0.0, 0.01)}
+    ref_s = {thr: np.packbits(orc.validity(qs.cpu().numpy(), thr, nthreads=8), bitorder="little") for thr in (0.0, 0.01)}
+
+    def bits(t, n):
+        return t.cpu().numpy().view(np.uint8)[: (n + 7) // 8]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sst = C.c_void_p(side.cuda_stream)
+        assert lib.nbk_validity_batch(dev._h, q.data_ptr(), B, 0.01, words.data_ptr(), None, sst) == 0       # allocates the scratch
+        side.synchronize()
+        assert np.array_equal(bits(words, B), ref[0.01])
+        g1 = torch.cuda.CUDAGraph()
+        g1.capture_begin()
+        assert lib.nbk_validity_batch(dev._h, q.data_ptr(), B, 0.01, words.data_ptr(), None, sst) == 0
+        g1.capture_end()
+        for round_ in range(2):
+            # two direct calls at another threshold (the second would have taken the cached-table path and counter set 1)
+            for _ in range(2):
+                words_s.zero_()
+                assert lib.nbk_validity_batch(dev._h, qs.data_ptr(), Bs, 0.0, words_s.data_ptr(), None, sst) == 0
+                side.synchronize()
+                assert np.array_equal(bits(words_s, Bs), ref_s[0.0])
+            words.zero_()
+            g1.replay()
+            side.synchronize()
+            assert np.array_equal(bits(words, B), ref[0.01])
+            # the direct call after the replay: smaller batch, other threshold (stale items of the replay would index beyond Bs)
+            words_s.zero_()
+            assert lib.nbk_validity_batch(dev._h, qs.data_ptr(), Bs, 0.0, words_s.data_ptr(), None, sst) == 0
+            side.synchronize()
+            assert np.array_equal(bits(words_s, Bs), ref_s[0.0])
+            # and one at the graph's own threshold
+            words_s.zero_()
+            assert lib.nbk_validity_batch(dev._h, qs.data_ptr(), Bs, 0.01, words_s.data_ptr(), None, sst) == 0
+            side.synchronize()
+            assert np.array_equal(bits(words_s, Bs), ref_s[0.01])
+    torch.cuda.current_stream().wait_stream(side)
+
+
 def test_edge_batches_beyond_the_scratch_capacity(fresh_world, torch_cuda):
     """connect() edges far longer than max_distance: the flat batch's capacity (E x (max_distance / resolution + 2) samples)
     overflows, the edges that do not fit are walked one wave each -- same bits; the device reports the true count through
@@ -1356,16 +1421,20 @@ def test_queue_overflow_is_redecided_without_a_queue(fresh_world, torch_cuda):
     assert np.array_equal(dev.validity(q, 0.0), refs[0.0])                 # and back at the default budget
 
 
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("scene", ["c2", "c3", "c5m"])
-def test_bullet_margin_mode(fresh_world, scene, torch_cuda):
-    """``Arm(chain, bullet_margins=True)``: every box / cylinder / mesh hull without an explicit margin gets the one Bullet applies
-    (min(0.04, a tenth of the smallest half extent); hulls 0.001) -- the scene closest to what the reference's getClosestPoints
-    measures.  Same bar as the sharp scenes: masks at four thresholds (all three validity paths), distances, witnesses and
-    gradient rows bit for bit against the oracle.  (Parity with Bullet itself stays unpinned.)"""
-    arm, chain, obs = build_scene(scene, bullet_margins=True)
+def test_bullet_margin_mode(fresh_world, scene, margins, torch_cuda):
+    """``Arm(chain)`` = ``bullet_margins=True`` (the default): every box / cylinder / mesh hull without an explicit margin gets the
+    one Bullet applies (min(0.04, a tenth of the smallest half extent); hulls 0.001) -- the scene closest to what the reference's
+    getClosestPoints measures; ``bullet_margins=False``: the sharp analytic shapes.  Same bar in both: masks at four thresholds
+    (all three validity paths), distances, witnesses and gradient rows bit for bit against the oracle.  (Parity with Bullet itself
+    stays unpinned.)"""
+    arm, chain, obs = build_scene(scene, bullet_margins=margins)
     sm = arm.scene_model()
-    assert (sm.rshape_param[:, 3] > 0).sum() >= 9 and (sm.wshape_param[:, 3] > 0).all()
-    sharp = build_scene  # noqa: F841
+    if margins:
+        assert (sm.rshape_param[:, 3] > 0).sum() >= 9 and (sm.wshape_param[:, 3] > 0).all()
+    else:
+        assert (sm.rshape_param[:, 3] == 0).all() and (sm.wshape_param[:, 3] == 0).all()
     orc = Oracle(sm)
     q = sample_q(chain, 20000, seed=2)
     for thr in (0.0, 1e-6, 0.02, -0.005):
@@ -1385,8 +1454,8 @@ def test_bullet_margin_mode(fresh_world, scene, torch_cuda):
     assert_bitwise(dmin, dref, "bullet-margin closest")
     assert np.array_equal(idx, iref)
     # switching the mode on an existing arm recompiles the scene
-    arm.bullet_margins = False
-    assert (arm.scene_model().rshape_param[:, 3] == 0).all()
+    arm.bullet_margins = not margins
+    assert ((arm.scene_model().rshape_param[:, 3] == 0).all()) == margins
     assert np.array_equal(arm.in_collision(q[:5000]), Oracle(arm.scene_model()).validity(q[:5000]))
 
 

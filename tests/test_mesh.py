@@ -69,6 +69,16 @@ def test_load_mesh_transform_sequence_and_center_of_mass(tmp_path):
     assert not np.allclose(center_of_mass(read_obj(g)), tetra.mean(axis=0))
     # convex_decomposition: a multi-object file IS the decomposition; a single object cannot be decomposed here
     assert len(load_mesh(os.path.join(MESH_DIR, "table.obj"), convex_decomposition=True)) == 5
+    assert len(mesh_hulls(os.path.join(MESH_DIR, "table.obj"), convex_decomposition=True)) == 5
+    # without it the objects of a file are ONE mesh (trimesh merges them before the reference exports the file for Bullet):
+    # one hull of all the vertices -- the table's top and the space between its legs are inside it
+    one = mesh_hulls(os.path.join(MESH_DIR, "table.obj"))
+    allv = np.concatenate([p.vertices for p in load_mesh(os.path.join(MESH_DIR, "table.obj"))])
+    assert len(one) == 1 and (((allv - one[0].center) @ one[0].planes[:, :3].T) <= one[0].planes[:, 3] + 1e-12).all()
+    under_the_top = np.array([allv[:, 0].mean(), allv[:, 1].mean(), 0.5 * (allv[:, 2].min() + allv[:, 2].max())])
+    assert ((under_the_top - one[0].center) @ one[0].planes[:, :3].T <= one[0].planes[:, 3]).all()
+    parts = mesh_hulls(os.path.join(MESH_DIR, "table.obj"), convex_decomposition=True)
+    assert not any((((under_the_top - h.center) @ h.planes[:, :3].T) <= h.planes[:, 3]).all() for h in parts)
     with pytest.raises(NotImplementedError):
         load_mesh(f, convex_decomposition=True)
 
@@ -89,10 +99,10 @@ def test_scene_compilation_with_mesh_links_and_mesh_obstacles(fresh_world):
     arm, chain, obs = build_scene("c5m")
     sm = arm.scene_model()
     assert sm.n_rshapes == 11 and (sm.rshape_type == 5).sum() == 10 and (sm.rshape_type == 0).sum() == 1
-    # bracelet_link: ONE <collision> element, a two-object file -> two hull primitives on that link (compound mesh)
+    # bracelet_link: two <collision> elements, one single-object file each -> two hull primitives on that link (compound)
     li = [l._name for l in sm.links].index("bracelet_link")
     assert (sm.rshape_link == li).sum() == 2
-    # obstacles: rock 1 + table 5 + wedge 1 hulls + 1 box
+    # obstacles: rock 1 + table 5 (its five objects, convex_decomposition=True) + wedge 1 hulls + 1 box
     assert sm.n_wshapes == 8 and (sm.wshape_type == 5).sum() == 7 and sm.n_hulls == 17
     assert sm.hull_vert_begin[-1] == len(sm.hull_verts) and sm.hull_face_begin[-1] == len(sm.hull_planes)
     # every hull is centred on the mean of its vertices and its planes contain all of its vertices
@@ -121,13 +131,13 @@ def test_scene_compilation_with_mesh_links_and_mesh_obstacles(fresh_world):
 def test_mesh_arm_is_never_closer_than_the_cylinder_arm(fresh_world):
     from numbotics_amd.physics.world import _reset_worlds
     from numbotics_amd.physics import World
-    arm, chain, obs = build_scene("c2m")
+    arm, chain, obs = build_scene("c2m", bullet_margins=False)         # the sharp shapes: hull vertices on the cylinders' surfaces
     q = sample_q(chain, 300, seed=5)
     dm = Oracle(arm.scene_model()).pair_distances(q)
     _reset_worlds(); World()
-    arm2, chain2, obs2 = build_scene("c2")
+    arm2, chain2, obs2 = build_scene("c2", bullet_margins=False)
     dc = Oracle(arm2.scene_model()).pair_distances(q)
-    assert dm.shape == dc.shape                 # same pair list: the compound bracelet file yields the same two primitives
+    assert dm.shape == dc.shape                 # same pair list: the compound bracelet link yields the same two primitives
     both = (dm > 1e-6) & (dc > 1e-6)
     assert both.mean() > 0.9 and (dm - dc)[both].min() > -1e-9
 

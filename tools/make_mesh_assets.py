@@ -2,10 +2,11 @@
 
   meshes/link_<name>.obj   faceted stand-ins for the Kinova fixture's collision cylinders: a 10-gon drum whose end caps are
                            chamfered rings (30 vertices, one convex object), in the SAME local frame as the cylinder it replaces
-  meshes/bracelet.obj      compound: drum + camera box as two objects of one file (one hull each)
+  meshes/bracelet_*.obj    compound link: drum + camera box, one single-object file per <collision> element (one hull each)
   meshes/gripper_base.obj  one box-like object with bevelled edges (24 vertices)
   meshes/rock.obj          a random convex polytope (obstacle)
-  meshes/table.obj         compound obstacle: top + four legs = five objects
+  meshes/table.obj         compound obstacle: top + four legs = five objects (loaded with convex_decomposition=True: the file is
+                           taken as its own decomposition; without the flag it is ONE hull, as in the reference)
   meshes/wedge.stl         binary STL obstacle (a triangular prism)
   kinova_mesh.urdf         kinova_cyl.urdf with every <cylinder>/<box> collision element replaced by a <mesh> (the sphere of
                            the gripper link stays a sphere), same joint tree
@@ -84,24 +85,21 @@ def main():
             continue
         new_body = body
         if name == "bracelet_link":
-            # compound link: both elements go into ONE mesh file with two objects, placed in the link frame
-            parts = []
+            # compound link: one single-object mesh file per <collision> element, placed in the link frame.  (A file with several
+            # objects would NOT stay a compound: the reference hands Bullet trimesh's re-export of the loaded file, and trimesh
+            # merges the objects of a single-material OBJ into one mesh -> one hull.  numbotics_amd/utils/mesh.py:mesh_hulls.)
             for i, cm in enumerate(colls):
                 xyz = np.array([float(v) for v in cm.group(1).split()])
                 g = cm.group(3)
                 if "cylinder" in g:
                     r, l = float(re.search(r'radius="([^"]+)"', g).group(1)), float(re.search(r'length="([^"]+)"', g).group(1))
-                    parts.append(obj_part(f"bracelet_drum", drum(r, l), xyz))
+                    fn, part = "meshes/bracelet_drum.obj", obj_part("bracelet_drum", drum(r, l), xyz)
                 else:
                     size = [float(v) for v in re.search(r'size="([^"]+)"', g).group(1).split()]
-                    parts.append(obj_part(f"bracelet_camera", bevel_box(size), xyz))
-            write_obj(os.path.join(MESHES, "bracelet.obj"), parts)
-            first = True
-            for cm in colls:
-                rep = ('<collision>\n      <origin xyz="0 0 0" rpy="0 0 0"/>\n      <geometry><mesh filename="meshes/bracelet.obj"/></geometry>\n    </collision>'
-                       if first else "")
+                    fn, part = "meshes/bracelet_camera.obj", obj_part("bracelet_camera", bevel_box(size), xyz)
+                write_obj(os.path.join(MODELS, fn), [part])
+                rep = ('<collision>\n      <origin xyz="0 0 0" rpy="0 0 0"/>\n      <geometry><mesh filename="' + fn + '"/></geometry>\n    </collision>')
                 new_body = new_body.replace(cm.group(0), rep)
-                first = False
         else:
             for cm in colls:
                 g = cm.group(3)
