@@ -3,7 +3,9 @@
 
 Workload (BASELINE.json configs[1]): Kinova-like 7-DoF arm, Arm.in_collision over a 1e6-q batch per GPU,
 self pairs (default rule minus the removals of _test_rrt.py:38-61) + one Cube(half_extent=0.4) at
-[1.0, 0.0, 0.2], threshold 0.  One "step" = one pass of the hot path over one batch: the validity kernels
+[1.0, 0.0, 0.2], threshold 0, in the DEFAULT shape mode: Bullet's own collision margins on every box / cylinder / hull
+(Arm(chain) = bullet_margins=True -- what pybullet.createCollisionShape builds for the reference, numbotics/utils/shape.py:60-109);
+`modes` carries the same step on the sharp analytic shapes (bullet_margins=False) beside it.  One "step" = one pass of the hot path over one batch: the validity kernels
 writing the packed bit mask, and for N > 1 the RCCL all-gather of every rank's mask words.  The timed loop rotates
 over 5 distinct q batches (5 x 56 MB = 280 MB > the 256 MiB Infinity Cache), so no step finds its input in cache.
 
@@ -13,7 +15,10 @@ over 5 distinct q batches (5 x 56 MB = 280 MB > the 256 MiB Infinity Cache), so 
 Rank 0 prints ONE JSON line.  `value` is whole-job configurations / wall time of the K timed steps (inputs resident in
 HBM).  Beside it, all timed with HIP events on the launch stream, median and min over >= 10 repetitions:
   roofline              the validity step against HBM as the contract asks (56 B of q + 1 bit per configuration); the
-                        step is VALU-bound by construction, `valu_issue` prices it against that roof
+                        step is arithmetic / latency-bound by construction; `valu_issue` prices it against vector
+                        issue per kernel dtype (float32 wave64 = 2 cycles on a SIMD-32, float64 = 4)
+  modes                 the headline step per shape mode (bullet margins = default = headline; sharp): which narrowphase build
+                        ran, per-step kernel time median / min / max over >= 20 rotating batches (the tail shows), configs/s
   end_to_end            the same step from HOST memory: H2D of q (pinned and pageable) + kernels + D2H of the mask words
   edge_roofline         BASELINE config 3: E = 1e5 DiscreteConnector edges, resolution 0.01, 8-cube ring
   records               BASELINE config 5: M = 10 071 samples, every pair's distance / contact points / normal / (P,7) row,
@@ -55,6 +60,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=0, help="total configurations per step, split over the ranks (strong scaling; "
                     "BASELINE config 4 is --global-batch 10000000)")
     ap.add_argument("--scene", default="c2")
+    ap.add_argument("--sharp", action="store_true", help="headline on the sharp analytic shapes (bullet_margins=False) instead of the "
+                    "default Bullet-margin shapes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the headline step (profiling runs)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the control flow)")
@@ -84,8 +91,9 @@ def main():
     from numbotics_amd.csrc.build import source_digest
 
     World()
-    arm, chain, obstacles = build_scene(args.scene)
+    arm, chain, obstacles = build_scene(args.scene, bullet_margins=not args.sharp)
     sm, dev = arm._scene_device()
+    mode_name = "sharp (bullet_margins=False)" if args.sharp else "bullet margins (default: Arm(chain), bullet_margins=True)"
     strong = args.global_batch > 0
     total = args.global_batch if strong else args.batch * world
     lo, hi = shard_bounds(total, world, rank)
@@ -216,22 +224,37 @@ def main():
         else:
             traffic_note = (f"{os.path.relpath(side[-1], ROOT)} was measured on kernel sources {tj.get('csrc_sha')}, this run is "
                             f"{digest}: PMC figures withheld")
-    roofline = {"bound": "hbm", "kernel": "k_broad_f32 + k_narrow_bool (one nbk_validity_batch call)",
+    narrow_build = dev.narrow_build(0.0)
+    roofline = {"bound": "hbm", "kernel": f"k_broad_f32 + {narrow_build} (one nbk_validity_batch call)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
                 "kernel_ms": kern_ms, "kernel_ms_median": kern["median_ms"], "kernel_ms_min": kern["min_ms"], "reps": kern["reps"],
                 "algorithmic_bytes": alg_bytes, "algorithmic_bytes_per_config": 8.0 * chain.dof + 0.125,
-                "note": "VALU-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md",
+                "kernel_ms_max": max(step_ms),
+                "note": "arithmetic / latency-bound by arithmetic intensity (SURVEY.md F8); see DESIGN.md",
                 "csrc_sha": digest, "valu": valu}
     if valu:
-        # the roof that does bound the step: vector-ALU issue (256 CUs x 4 SIMDs, one wave64 instruction per 4 cycles at
-        # 2.4 GHz).  Instruction counts per wave from the SQ pass of the profile the traffic comes from, time from this run.
+        # vector-ALU issue, per kernel dtype (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32,
+        # float64 at half rate = 4): 256 CUs x 4 SIMDs at 2.4 GHz.  Instruction counts per wave from the SQ pass of the profile the
+        # traffic comes from (same kernel sources), time from this run.  `frac` = the SIMD-cycles the step's VALU stream needs
+        # over the SIMD-cycles the step lasted -- an upper bound (integer / move instructions of the float64 kernels priced at 4).
         step_k = [k for k in ("k_broad_f32", "k_broad_reg", "k_broad", "k_narrow") if k in valu]
-        insts = sum(valu[k]["valu_insts_per_wave"] * valu[k]["waves"] for k in step_k) * (B / float(tj.get("batch", B)))
-        peak = 1024 * 2.4e9 / 4.0
-        roofline["valu_issue"] = {"bound": "valu", "achieved": insts / (kern_ms * 1e-3), "peak": peak, "unit": "wave-instructions/s",
-                                  "frac": insts / (kern_ms * 1e-3) / peak, "wave_instructions_per_step": insts,
-                                  "wave_instructions_per_config": insts / B, "kernels": step_k}
+        sc = B / float(tj.get("batch", B))
+        per = {}
+        need_cycles = 0.0
+        for k in step_k:
+            cyc = 2.0 if k == "k_broad_f32" else 4.0
+            n = valu[k]["valu_insts_per_wave"] * valu[k]["waves"] * sc
+            per[k] = {"dtype": "f32" if cyc == 2.0 else "f64", "cycles_per_wave_instruction": cyc, "wave_instructions": n,
+                      "peak_wave_instructions_per_s": 1024 * 2.4e9 / cyc, "simd_issue_ms": n * cyc / (1024 * 2.4e9) * 1e3,
+                      "salu_insts_per_wave": valu[k].get("salu_insts_per_wave"),
+                      "salu_issue_us_one_unit_per_cu": valu[k].get("salu_issue_us_one_unit_per_cu"),
+                      "s_waitcnt_share_of_wave_lifetime": valu[k].get("wait_fraction_of_wave_lifetime")}
+            need_cycles += n * cyc
+        insts = sum(v["wave_instructions"] for v in per.values())
+        roofline["valu_issue"] = {"bound": "valu", "achieved": need_cycles / (kern_ms * 1e-3), "peak": 1024 * 2.4e9,
+                                  "unit": "SIMD issue cycles/s", "frac": need_cycles / (kern_ms * 1e-3) / (1024 * 2.4e9),
+                                  "wave_instructions_per_step": insts, "wave_instructions_per_config": insts / B, "kernels": per}
 
     out = {
         "metric": "collision-checked configs/sec, Kinova 7-DoF + obstacles",
@@ -240,10 +263,11 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Arm.in_collision, Kinova-like 7-DoF (build-authored kinova_cyl.urdf), scene {args.scene}: "
                                f"{sm.n_pairs} primitive pairs ({sm.n_rshapes} robot shapes, {sm.n_wshapes} obstacle), "
-                               f"{B} q per GPU per step, threshold 0, packed bit mask; the timed loop rotates over {N_ROTATE} distinct "
+                               f"{B} q per GPU per step, threshold 0, shape mode: {mode_name}, narrowphase build {narrow_build}, packed bit mask; the timed loop rotates over {N_ROTATE} distinct "
                                f"q batches ({N_ROTATE * B * 8 * chain.dof / 2**20:.0f} MiB)"
                                + (", RCCL all-gather of mask words" if world > 1 else ""),
                    "batch_per_gpu": B, "global_batch": total, "pairs": sm.n_pairs, "parallelism": f"dp{world}",
+                   "shape_mode": "sharp" if args.sharp else "bullet_margins", "narrowphase_build": narrow_build,
                    "mask_gather": ("none" if world == 1 else ("overlapped with the next step" if state["overlap"] else "serial")),
                    "arithmetic": "float32 broadphase culls / certifies with a slack that only lets it decide what float64 would decide the "
                                  "same way; every other verdict is computed in float64; the mask is bit-exact vs the CPU oracle on the sample"},
@@ -253,6 +277,41 @@ def main():
         "parity_note": "GPU vs this build's CPU oracle (oracle/); parity of collision values vs the reference's PyBullet is UNPINNED "
                        "(third-party, absent, no reference fixture) -- FK / Jacobian / edge sampling are pinned by reference-generated golden vectors",
     }
+
+    # ---- the headline step per shape mode: >= 20 steps rotating over the q batches, one HIP event pair per step (the tail shows) ----
+    def mode_object(dev_x, thr=0.0, reps=20):
+        for k in range(3):
+            dev_x.validity(qs[k % N_ROTATE], thr, packed=True)
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        evs[0].record()
+        for k in range(reps):
+            dev_x.validity(qs[k % N_ROTATE], thr, packed=True)
+            evs[k + 1].record()
+        torch.cuda.synchronize()
+        ms = [evs[k].elapsed_time(evs[k + 1]) for k in range(reps)]
+        st = stats_ms(ms)
+        return {"narrowphase_build": dev_x.narrow_build(thr), "kernel_ms_median": st["median_ms"], "kernel_ms_min": st["min_ms"],
+                "kernel_ms_max": max(ms), "kernel_ms_mean": st["mean_ms"], "reps": reps, "rotating_batches": N_ROTATE,
+                "configs_per_s": B / (st["median_ms"] * 1e-3)}
+    modes = {"what": "one nbk_validity_batch call per step at threshold 0, 1e6 q per step rotating over the headline's batches; "
+                     "HIP events on the launch stream around every step",
+             "headline_mode": "sharp" if args.sharp else "bullet_margins"}
+    modes["sharp" if args.sharp else "bullet_margins"] = mode_object(dev)
+    arm.bullet_margins = bool(args.sharp)                 # the other mode: recompiles the scene into a second descriptor
+    sm_o, dev_o = arm._scene_device()
+    other = mode_object(dev_o)
+    wo = dev_o.validity(qs[0], 0.0, packed=True).cpu().numpy().view(np.uint64)
+    bo = ((wo[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).reshape(-1)[:B]
+    other_ok = bool(np.array_equal(bo[sl], Oracle(sm_o).validity(q_host[sl], 0.0, nthreads=8)))
+    other["parity_vs_oracle"] = ("bit-exact" if other_ok else "MISMATCH") + f" on {sl.size} configurations"
+    other["collision_fraction"] = float(bo.mean())
+    modes["bullet_margins" if args.sharp else "sharp"] = other
+    modes["sharp" if args.sharp else "bullet_margins"]["collision_fraction"] = coll_frac
+    out["modes"] = modes
+    parity_ok = parity_ok and other_ok
+    arm.bullet_margins = not args.sharp
+    del dev_o
 
     if not args.no_extras:
         # ---- end to end from host memory: H2D q + kernels + D2H mask words (PCIe inclusive; never `value`) ---------------

@@ -98,6 +98,7 @@ def load():
     lib.nbk_validity_scalar_host.argtypes = [vp, vp, f64, vp]
     lib.nbk_edge_validity_scalar_host.argtypes = [vp, vp, vp, f64, f64, f64, i32, f64, vp, vp, vp]
     lib.nbk_debug_set_option.argtypes = [C.c_char_p, i64]
+    lib.nbk_debug_narrow_variant.argtypes = [vp, f64]
     _lib = lib
     return lib
 

@@ -3976,6 +3976,25 @@ static inline int64_t call_tile(const nbk_model* m, const PairCounts& pc, int64_
     return pipe && t > PIPE_TILE ? PIPE_TILE : t;
 }
 
+// which GJK walks can a call at this threshold need?  tc = (thr + mA) + mB per pair that can reach GJK: all zero and no hull -> the
+// boolean walk only (0: k_narrow_bool); none negative -> the (inflated) walk + the distance iteration for hulls and undecided walks
+// (1: k_narrow_pos); all negative -> the distance predicate only (2: k_narrow_pred); else the build with everything (3: k_narrow)
+static int narrow_variant(const nbk_model* m, double threshold) {
+    bool any_zero = false, any_positive = false, any_negative = false;
+    for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
+        const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
+        if (tc == 0.0) any_zero = true;
+        else if (tc > 0.0) any_positive = true;
+        else any_negative = true;                      // (a NaN threshold counts as negative: the distance predicate)
+    }
+    if (!any_positive && !any_negative && !m->gjk_any_hull) return 0;
+    if (!any_negative) return 1;
+    if (!any_zero && !any_positive) return 2;
+    return 3;
+}
+// diagnostic (not part of include/nbk.h): the narrowphase build nbk_validity_batch picks for this descriptor at this threshold
+extern "C" int32_t nbk_debug_narrow_variant(const nbk_model* m, double threshold) { return m == nullptr ? NBK_ERR_INVALID : narrow_variant(m, threshold); }
+
 // `pipe` (the library's own scratch only): odd tiles run on iw0->aux_stream with the scratch set iw0->aux
 static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, EdgeSrc es, const double* q, int64_t B, double threshold, uint64_t* mask_bits,
                                       uint8_t* mask_bytes, void* workspace0, hipStream_t st0, StreamWs* iw0, bool pipe) {
@@ -3987,13 +4006,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
     // which GJK walks can this call need?  tc = (thr + mA) + mB per pair: all zero and no hull -> boolean walk only, none negative ->
     // the (inflated) walk + the distance iteration for hulls and undecided walks, all negative -> distance predicate only, else
     // the build with everything
-    bool any_zero = false, any_positive = false, any_negative = false;
-    for (size_t i = 0; i + 1 < m->gjk_margins.size(); i += 2) {
-        const double tc = (threshold + m->gjk_margins[i]) + m->gjk_margins[i + 1];
-        if (tc == 0.0) any_zero = true;
-        else if (tc > 0.0) any_positive = true;
-        else any_negative = true;                      // (a NaN threshold counts as negative: the distance predicate)
-    }
+    const int narrow_build = narrow_variant(m, threshold);
     const int S = m->d.n_rshapes;
     const bool use_reg = S <= 16 && (!g_opt.no_reg_broad || !m->lds_broad_ok);
     const bool f32 = !g_opt.f64_broad || broad_reg_lds(m, S <= 8 ? 8 : (S <= 12 ? 12 : 16)) > 160 * 1024;   // the float64 form keeps its tables in LDS
@@ -4061,11 +4074,11 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         unsigned parts = 4u * nblk / NSUB;
         { const unsigned pmax = g_opt.narrow_parts_max > 0 ? (unsigned)g_opt.narrow_parts_max : 16u; parts = parts < 4u ? 4u : parts; parts = parts > pmax ? pmax : parts; }
         if (nblk <= 4u) parts = 1u;                      // a handful of configurations (the scalar calls): 256 workgroups are plenty
-        if (!any_positive && !any_negative && !m->gjk_any_hull)
+        if (narrow_build == 0)
             hipLaunchKernelGGL(k_narrow_bool, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
-        else if (!any_negative)
+        else if (narrow_build == 1)
             hipLaunchKernelGGL(k_narrow_pos, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
-        else if (!any_zero && !any_positive)
+        else if (narrow_build == 2)
             hipLaunchKernelGGL(k_narrow_pred, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);
         else
             hipLaunchKernelGGL(k_narrow, dim3(NSUB * parts), dim3(NARROW_T), nlds, st, m->d, es_tile, qt, threshold, items, count, cap_sub, mb, my, count_next);

@@ -229,6 +229,12 @@ class DeviceModel:
                                                        self._stream()), "nbk_validity_batch_ws")
         return qs.out(words) if packed else qs.out(mask.bool())
 
+    NARROW_BUILDS = ("k_narrow_bool", "k_narrow_pos", "k_narrow_pred", "k_narrow")
+
+    def narrow_build(self, threshold=0.0) -> str:
+        """Diagnostic: the narrowphase build ``validity`` launches for this scene at this threshold (bench.py reports it)."""
+        return self.NARROW_BUILDS[int(self._lib.nbk_debug_narrow_variant(self._h, float(threshold)))]
+
     def validity_scalar(self, q, threshold=0.0) -> bool:
         """One configuration from host memory (the reference's scalar ``in_collision(q)``): pinned, device-mapped staging
         inside the library, one wait -- no torch tensors on the way."""

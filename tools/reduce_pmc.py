@@ -25,7 +25,13 @@ sys.path.insert(0, ROOT)
 from numbotics_amd.csrc.build import source_digest      # the json records which kernel sources the counters belong to
 N_SIMD = 256 * 4
 CLOCK_HZ = 2.4e9
-VALU_F64_CYCLES = 4          # one wave64 float64 VALU instruction occupies its SIMD for 4 cycles (16 lanes/cycle)
+# vector-ALU issue cost of one wave64 instruction on a CDNA4 SIMD-32 with other waves interleaved (MI355X_MICROARCH.md: "A wave
+# (64 lanes) ... issues each VALU instruction over 2 cycles"; constants table: v_fma_f32 wave64 2 cyc): float32 / integer 2 cycles,
+# float64 4 (half rate).  Kernels are priced by the type their arithmetic is in: the float32 broadphase at 2, everything else
+# (float64 sweeps, GJK, FK) at 4 -- their integer / move instructions are then over-priced, which makes the utilisation an UPPER bound.
+VALU_CYCLES = {"k_broad_f32": 2}
+VALU_CYCLES_DEFAULT = 4
+N_CU = 256
 
 KERNELS = {"k_broad_f32": "nbk::k_broad_f32", "k_broad_reg": "nbk::k_broad_reg", "k_broad": "nbk::k_broad(", "k_narrow": "nbk::k_narrow",
            "k_fk_frames": "nbk::k_fk_frames", "k_fk": "nbk::k_fk(", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
@@ -94,9 +100,18 @@ def main():
                  "lds_insts_per_wave": mean(c["SQ_INSTS_LDS"]) / waves,
                  "kernel_us_under_pmc": mean(sq_dur[k]) / 1e3}
             # SQ_WAVE_CYCLES / SQ_WAIT_INST_ANY count quad-cycles.  Direct estimates over the launch at the nominal
-            # 2.4 GHz engine clock: VALU instructions x 4 cycles (float64 wave64) over the SIMD-cycles available.
+            # 2.4 GHz engine clock: VALU instructions x their issue cycles over the SIMD-cycles available.
             cyc = mean(sq_dur[k]) * 1e-9 * CLOCK_HZ
-            d["simd_valu_issue_utilisation"] = insts * VALU_F64_CYCLES / (N_SIMD * cyc)
+            vc = VALU_CYCLES.get(k, VALU_CYCLES_DEFAULT)
+            d["valu_cycles_per_wave_instruction"] = vc
+            d["simd_valu_issue_utilisation"] = insts * vc / (N_SIMD * cyc)
+            # the scalar side: ONE scalar unit per CU serves all of its waves; at one scalar instruction per cycle the launch's
+            # SALU stream alone takes this long (a floor for the kernel if nothing else overlapped)
+            salu = mean(c["SQ_INSTS_SALU"])
+            d["salu_issues_per_cu"] = salu / N_CU
+            d["salu_issue_us_one_unit_per_cu"] = salu / N_CU / CLOCK_HZ * 1e6
+            d["salu_share_of_kernel_time"] = d["salu_issue_us_one_unit_per_cu"] / d["kernel_us_under_pmc"]
+            d["s_waitcnt_share_of_wave_lifetime"] = d["wait_fraction_of_wave_lifetime"]
             d["resident_waves_per_simd"] = mean(c["SQ_WAVE_CYCLES"]) * 4 / (N_SIMD * cyc)
             if clk and k in clk and "GRBM_GUI_ACTIVE" in clk[k]:
                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs and includes the dispatch overhead around short kernels:
