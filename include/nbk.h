@@ -184,7 +184,8 @@ int32_t nbk_validity_batch(const nbk_model *m, const double *q, int64_t B, doubl
  * more than 512 pairs; larger batches are processed in tiles of that size.
  * nbk_validity_batch itself keeps one internal workspace per (descriptor, stream), grown with hipMalloc on demand: calls on
  * different streams share nothing and overlap; use this variant when the memory must be the caller's (allocator pools,
- * graphs that outlive a regrowth of the internal scratch).
+ * graphs that outlive a regrowth of the internal scratch).  `workspace` must be 64-byte aligned (hipMalloc / torch allocations
+ * are): NBK_ERR_INVALID otherwise.
  */
 int64_t nbk_validity_workspace_bytes(const nbk_model *m, int64_t B);
 int32_t nbk_validity_batch_ws(const nbk_model *m, const double *q, int64_t B, double threshold,

@@ -68,6 +68,9 @@ struct DevModel {
     // the configuration) covers the float32 error of the sweep 50 times over
     const float* f_tab;
     int f_trans, f_slide, f_base, f_tl, f_wc, f_wobb;      // f_wobb: [W][6] local bounding boxes of world hulls (centre, half extents)
+    int f_pk;                     // [J][20] per-joint constants of the packed float32 sweep (JPk), 16-byte aligned
+    int f_meta;                   // [8] dwords (bit patterns): joint kind | q column << 8 of the first 8 joints
+    int f_chain;                  // 1: a serial chain of at most 8 joints without saved frames -- k_broad_f32 unrolls its joints at compile time
     float f_eps, f_reach;
     float f_e2max;                // static bound of the per-lane slack 2e: lanes above it (prismatic travel, |q| sums beyond 64 rad) do not certify hits
     const double* rs_in;          // [S] radius of a ball around the shape's centre that lies inside the shape (margin included)
@@ -1206,6 +1209,10 @@ __global__ __launch_bounds__(64) void k_validity_redo(DevModel m, EdgeSrc es, co
 // Both kernels evaluate exactly the predicate of the fused kernel (and of the oracle), so the masks are
 // bit-identical; the fused kernel stays for small batches and for the edge kernel.
 constexpr int BQ_CAP = 512;             // per-wave LDS staging of queue items before one global append
+// k_broad_f32<S>: rows of 64 doubles its q slab / item queue takes.  The queue must hold one whole row of slots (S x 64 items)
+// beyond what is pending, so that the "queue nearly full" test -- and with it the inlined flush -- exists once per row / world
+// shape instead of once per slot (92 inlined flushes made the kernel 195 KB of code for a 64 KB instruction cache)
+__host__ __device__ constexpr int f32_qrows(int nq, int S) { return nq > (S + 2) / 2 ? nq : (S + 2) / 2; }
 
 NBK_DEV double readlane_f64(double v, int l) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -1273,22 +1280,30 @@ __global__ void k_zero_counters(unsigned long long* __restrict__ q_count, unsign
 //   wcin [W*16] float  world boxes: (thr + inA + mBox - f_e2max)^2 against the centre's squared distance to the (core) box
 //   rptri[128]  int    sorted pair index of robot-robot slot (a,b) at its triangular index b(b-1)/2 + a
 //   wlist[W], n_reach  int   the world shapes some robot shape can reach at this threshold, ascending; the world loop visits only those
-//   rkey2[16*16], wkey2[W*16] float  the candidate thresholds with the STATIC slack folded in and squared ((rs + f_e2max)^2; planes: the
+//   rneg[16*16], rnd[16*16] float  robot-robot slots of the fast stage: e = |ca - cb|^2 + rneg (an fma chain that starts from rneg =
+//               -(rs + f_e2max)^2, the candidate threshold with the STATIC slack folded in, squared and rounded up) is negative for a
+//               candidate, f = e + rnd (rnd = that threshold minus the certification threshold) for a certified hit; +1 / +3e38 = never
+//   wbx[W][8][12] float  world BOXES, fast stage, per pair of robot shapes (2i, 2i + 1): (wkey2 | cull2 | cin | kin | g) x 2 -- the
+//               sphere threshold, ((tc+ + rhoA) + f_e2max)^2 for the centre's squared distance to the core box (farther: free),
+//               the certification thresholds outside / inside, the depth the centre must exceed inside; see the kernel
+//   wkey2[W*16] float  the candidate thresholds of the world slots with the static slack folded in and squared ((rs + f_e2max)^2; planes: the
 //               height rs + rhoA + f_e2max): scalars for the waves whose lanes all stay within the static slack
-NBK_DEV size_t ftab_entries(int W) { return 4 * 256 + 128 + 6 * (size_t)W * 16 + 32 + (size_t)W + 16; }
+NBK_DEV size_t ftab_entries(int W) { return 5 * 256 + 128 + 6 * (size_t)W * 16 + 32 + (size_t)W + 16 + 96 * (size_t)W + 16; }
 struct FTab {
-    const float *rkey, *rcert, *wkey, *wtc, *wcert, *wcin, *rho, *rkey2, *wkey2;
+    const float *rkey, *rcert, *wkey, *wtc, *wcert, *wcin, *rho, *rneg, *rnd, *wkey2, *wbx;
     const int *rp, *rptri, *wp, *wlist, *n_reach;
 };
 NBK_DEV FTab ftab_view(const float* tab, int W) {
     FTab t;
     const size_t w16 = (size_t)W * 16;
+    // every [.][16] table starts on a multiple of 16 floats from `tab` (itself 64-byte aligned): a row is one s_load_dwordx16
     t.rkey = tab; t.rp = reinterpret_cast<const int*>(tab + 256); t.rcert = tab + 512;
     t.rptri = reinterpret_cast<const int*>(tab + 768);
-    t.wkey = tab + 896; t.wtc = t.wkey + w16; t.wp = reinterpret_cast<const int*>(t.wtc + w16);
-    t.wcert = t.wtc + 2 * w16; t.wcin = t.wcert + w16; t.rho = t.wcin + w16;
+    t.rneg = tab + 896; t.rnd = tab + 1152;
+    t.wkey = tab + 1408; t.wtc = t.wkey + w16; t.wp = reinterpret_cast<const int*>(t.wtc + w16);
+    t.wcert = t.wtc + 2 * w16; t.wcin = t.wcert + w16; t.wkey2 = t.wcin + w16; t.rho = t.wkey2 + w16;
     t.n_reach = reinterpret_cast<const int*>(t.rho + 32); t.wlist = t.n_reach + 16;
-    t.rkey2 = reinterpret_cast<const float*>(t.wlist + W); t.wkey2 = t.rkey2 + 256;
+    t.wbx = reinterpret_cast<const float*>(t.wlist + ((W + 15) & ~15));        // (16-float aligned)
     return t;
 }
 
@@ -1309,12 +1324,14 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
         const float v = (float)c * dn - m.f_e2max * up;
         return v > 0.0f ? (v * v) * (dn * dn) : -1.0f;
     };
-    float* rkey2 = const_cast<float*>(v.rkey2); float* wkey2 = const_cast<float*>(v.wkey2);
+    float* rneg = const_cast<float*>(v.rneg); float* rnd = const_cast<float*>(v.rnd); float* wkey2 = const_cast<float*>(v.wkey2);
     // squared candidate threshold with the static slack: ((rs rounded up) + f_e2max)^2 rounded up; -1 = not a pair
     auto cand2 = [&](float rs_up) { const float r = (rs_up + m.f_e2max) * up; return (r * r) * (up * up); };
-    rkey[t] = -1.0f; rp[t] = -1; rcert[t] = -1.0f; rkey2[t] = -1.0f;
+    rkey[t] = -1.0f; rp[t] = -1; rcert[t] = -1.0f; rneg[t] = 1.0f; rnd[t] = 3.0e38f;
     if (t < 128) rptri[t] = -1;
     for (int i = t; i < W * 16; i += 256) { wkey[i] = -1.0f; wtc[i] = 0.0f; wp[i] = -1; wcert[i] = -3.0e38f; wcin[i] = -1.0f; wkey2[i] = -3.0e38f; }
+    float* wbx = const_cast<float*>(v.wbx);
+    for (int i = t; i < W * 96; i += 256) { const int f = (i % 12) / 2; wbx[i] = f == 0 ? -3.0e38f : (f == 1 ? 0.0f : (f == 4 ? 3.0e38f : -1.0f)); }
     if (t < 16) rho[t] = t < m.n_rshapes ? (float)m.rs_core[6 * t + 5] * up : 0.0f;
     __syncthreads();
     const int P = (NBK_DBG(m) & 2) ? 0 : m.n_pairs;
@@ -1328,10 +1345,19 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
             const double rs = (tc + cst[2]) + cst[3];
             const int lo = a < b ? a : b, hi = a < b ? b : a;
             rkey[lo * 16 + hi] = rs > 0.0 ? (float)rs * up : -1.0f;
-            rkey2[lo * 16 + hi] = rs > 0.0 ? cand2((float)rs * up) : -1.0f;
             rp[lo * 16 + hi] = p;
             rptri[hi * (hi - 1) / 2 + lo] = p;
-            rcert[lo * 16 + hi] = cert2((thr + m.rs_in[a]) + m.rs_in[b]);
+            const float ce = cert2((thr + m.rs_in[a]) + m.rs_in[b]);
+            rcert[lo * 16 + hi] = ce;
+            // the fast stage evaluates e = fma(dz, dz, fma(dy, dy, fma(dx, dx, -k2))) and f = e + (k2 - ce'): four roundings of at
+            // most 2^-24 max(k2, |d|^2) each.  k2 carries 1e-6 of itself on top of the candidate threshold (a cull e >= 0 still
+            // implies |d|^2 >= that threshold), ce' gives up 1e-6 k2 (f < 0 still implies |d|^2 < ce); k2 - ce' is rounded up
+            if (rs > 0.0) {
+                const float k2 = cand2((float)rs * up) * (1.0f + 1.0e-6f);
+                rneg[lo * 16 + hi] = -k2;
+                const float cea = ce > 0.0f ? ce * dn - 1.0e-6f * k2 : -1.0f;
+                rnd[lo * 16 + hi] = cea > 0.0f ? (k2 - cea) * up : 3.0e38f;
+            }
         } else {
             const int w = bt[1];
             // static reach culling: this world shape is out of the shape's reach for this threshold, whatever q is
@@ -1360,6 +1386,18 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
             wkey2[w * 16 + a] = cat == 0 ? ((key + rho[a]) + m.f_e2max * up) + __builtin_fabsf(key + rho[a]) * 2.4e-7f
                                          : (key >= 0.0f ? cand2(key) : -1.0f);
             wp[w * 16 + a] = p;
+            if (cat != 0 && m.ws_kind[w] == K_BOX) {
+                // the fast stage's box slot (every threshold with the STATIC slack bound, so that it is a scalar): see k_broad_f32
+                float* wb = wbx + w * 96 + (a / 2) * 12 + (a % 2);
+                const double tc = (thr + cst[0]) + cst[1];
+                const float tcp = tc > 0.0 ? (float)tc * up : 0.0f;
+                const float rr = ((tcp + rho[a]) + m.f_e2max * up) * up;
+                wb[0] = wkey2[w * 16 + a];
+                wb[2] = (rr * rr) * (up * up);                                   // centre farther from the core box than this: free
+                wb[4] = wcin[w * 16 + a];                                        // closer than this (and outside): certain hit
+                wb[6] = key > m.f_e2max * up ? ((key - m.f_e2max * up) * (key - m.f_e2max * up)) * (dn * dn * dn) : -1.0f;   // inside + within this sphere ...
+                wb[8] = ((float)(-tc) + __builtin_fabsf((float)tc) * 2.4e-7f) + m.f_e2max * up;                               // ... + deeper than this: certain hit
+            }
         }
     }
     // ---- the world shapes that are still somebody's pair, in ascending order ---------------------------------------------
@@ -1449,6 +1487,9 @@ __global__ __launch_bounds__(64) void k_broad(DevModel m, EdgeSrc es, const doub
     } else {
         const int total = rows_i * nq;
         const double* src = q + base * nq;
+#if defined(NBK_BF32_ABL) && NBK_BF32_ABL == 3      // timing experiment: no global read of q
+        if (true) { for (int i = lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.001 * (double)(i + (int)blockIdx.x); } else
+#endif
         if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
             const double2* s2 = reinterpret_cast<const double2*>(src);
             double2* d2 = reinterpret_cast<double2*>(lds_raw);
@@ -1635,6 +1676,9 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
     } else {
         const int total = rows_i * nq;
         const double* src = q + base * nq;
+#if defined(NBK_BF32_ABL) && NBK_BF32_ABL == 3      // timing experiment: no global read of q
+        if (true) { for (int i = lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.001 * (double)(i + (int)blockIdx.x); } else
+#endif
         if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
             const double2* s2 = reinterpret_cast<const double2*>(src);
             double2* d2 = reinterpret_cast<double2*>(lds_raw);
@@ -1893,8 +1937,93 @@ NBK_DEV void joint_apply_f(const DevModel& m, int k, const XfF& P, float qk, XfF
     }
 }
 
+struct alignas(64) Row16f { float v[16]; };     // one row of a [.][16] slot table: a single s_load_dwordx16
+typedef float V2f __attribute__((ext_vector_type(2)));
+typedef int V2i __attribute__((ext_vector_type(2)));
+// |d|^2 + nk as one fma chain, for two slots at a time (v_pk_fma_f32) and for one: the same operations in the same order, so the
+// one-slot form reproduces the pair form's value bit for bit (the rare enqueue path re-evaluates what the row's sign bits flagged)
+NBK_DEV V2f slot_e2(V2f dx, V2f dy, V2f dz, V2f nk) {
+    return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, nk)));
+}
+NBK_DEV float slot_e1(float dx, float dy, float dz, float nk) { return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, __builtin_fmaf(dx, dx, nk))); }
+
+// ---- the packed float32 sweep of k_broad_f32 --------------------------------------------------------------------------------
+// A frame as rows 0 and 1 of every column in one register PAIR (Rc[k] = (R[0][k], R[1][k]), tc = (t[0], t[1])) and row 2 apart:
+// R x L and R x v then run rows 0 and 1 together on v_pk_fma_f32 (one issue slot for two multiply-adds; plain float32 and packed
+// float32 instructions issue at the same rate on this SIMD, profiles/r03_valu_issue_rate.log): 27 instructions per axis-aligned
+// joint instead of 48, 6 per shape centre instead of 9.
+struct XfP { V2f Rc[3]; float R2[3]; V2f tc; float t2; };
+// host-made constants of one joint (f_tab + f_pk + 20 k): for a joint about coordinate axis KZ of its frame, U = KZ + 1, V = KZ + 2
+struct alignas(16) JPk { float m2p[6]; float m1p[6]; float mk[3]; float pad0; float toff[3]; float pad1; };
+NBK_DEV V2f splat2(float x) { return V2f{x, x}; }
+NBK_DEV V2f fma2(V2f a, V2f b, V2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int KZ>
+NBK_DEV void joint_apply_axis_p(const JPk& jp, const XfP& P, float s, float c, XfP& o) {
+    constexpr int U = (KZ + 1) % 3, V = (KZ + 2) % 3;
+    const V2f s2 = splat2(s), c2 = splat2(c);
+    V2f Lp[3];                                                     // (L[r][U], L[r][V]) = s M2 - c M1
+#pragma unroll
+    for (int r = 0; r < 3; ++r) Lp[r] = fma2(s2, V2f{jp.m2p[2 * r], jp.m2p[2 * r + 1]}, -(c2 * V2f{jp.m1p[2 * r], jp.m1p[2 * r + 1]}));
+    const V2f cu = fma2(P.Rc[2], splat2(Lp[2].x), fma2(P.Rc[1], splat2(Lp[1].x), P.Rc[0] * splat2(Lp[0].x)));
+    const V2f cv = fma2(P.Rc[2], splat2(Lp[2].y), fma2(P.Rc[1], splat2(Lp[1].y), P.Rc[0] * splat2(Lp[0].y)));
+    const V2f ck = fma2(P.Rc[2], splat2(jp.mk[2]), fma2(P.Rc[1], splat2(jp.mk[1]), P.Rc[0] * splat2(jp.mk[0])));
+    const V2f r2 = fma2(splat2(P.R2[2]), Lp[2], fma2(splat2(P.R2[1]), Lp[1], splat2(P.R2[0]) * Lp[0]));        // row 2, columns U and V
+    const float r2k = __builtin_fmaf(P.R2[2], jp.mk[2], __builtin_fmaf(P.R2[1], jp.mk[1], P.R2[0] * jp.mk[0]));
+    const V2f tc = fma2(P.Rc[2], splat2(jp.toff[2]), fma2(P.Rc[1], splat2(jp.toff[1]), fma2(P.Rc[0], splat2(jp.toff[0]), P.tc)));
+    const float t2 = __builtin_fmaf(P.R2[2], jp.toff[2], __builtin_fmaf(P.R2[1], jp.toff[1], __builtin_fmaf(P.R2[0], jp.toff[0], P.t2)));
+    o.Rc[U] = cu; o.Rc[V] = cv; o.Rc[KZ] = ck;
+    o.R2[U] = r2.x; o.R2[V] = r2.y; o.R2[KZ] = r2k;
+    o.tc = tc; o.t2 = t2;
+}
+
+// same case split as joint_apply_f; the error of every form is covered by the slack
+NBK_DEV void joint_apply_p(const DevModel& m, int k, int kind, const JPk& jp, const XfP& P, float qk, XfP& o) {
+    float s = 0.0f, c = 0.0f;
+    if (kind != JK_PRISMATIC) sincos_f(qk, s, c);
+    if (kind <= 2) {
+        if (kind == 0) joint_apply_axis_p<0>(jp, P, s, c, o);
+        else if (kind == 1) joint_apply_axis_p<1>(jp, P, s, c, o);
+        else joint_apply_axis_p<2>(jp, P, s, c, o);
+        return;
+    }
+    const float* M = m.f_tab + 27 * k;
+    const float* toff = m.f_tab + m.f_trans + 3 * k;
+    const float* sl = m.f_tab + m.f_slide + 3 * k;
+    float L[9], tl[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) L[e] = __builtin_fmaf(s, M[18 + e], __builtin_fmaf(-c, M[9 + e], M[e]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tl[i] = __builtin_fmaf(qk, sl[i], toff[i]);
+    XfP n;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        n.Rc[j] = fma2(P.Rc[2], splat2(L[6 + j]), fma2(P.Rc[1], splat2(L[3 + j]), P.Rc[0] * splat2(L[j])));
+        n.R2[j] = __builtin_fmaf(P.R2[2], L[6 + j], __builtin_fmaf(P.R2[1], L[3 + j], P.R2[0] * L[j]));
+    }
+    n.tc = fma2(P.Rc[2], splat2(tl[2]), fma2(P.Rc[1], splat2(tl[1]), fma2(P.Rc[0], splat2(tl[0]), P.tc)));
+    n.t2 = __builtin_fmaf(P.R2[2], tl[2], __builtin_fmaf(P.R2[1], tl[1], __builtin_fmaf(P.R2[0], tl[0], P.t2)));
+    o = n;
+}
+
+// in-kernel phase timing of k_broad_f32, only in builds made with -DNBK_BF32_STAMP (tools/build_variant.sh, tools/broad_prof.py):
+// per wave the cycles between stamps, summed over the launch -- [0] prologue (q slab into LDS), [1] sweep, [2] world shapes,
+// [3] robot-robot rows, [4] final flush + mask, [7] waves
+#ifdef NBK_BF32_STAMP
+__device__ unsigned long long g_broad_prof[16384 * 8];     // one slot per block (mod 16384): plain adds, no contention
+#else
+__device__ unsigned long long g_broad_prof[8];
+#endif
+#ifdef NBK_BF32_STAMP
+#define NBK_BSTAMP(i) do { __builtin_amdgcn_s_waitcnt(0); bstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define NBK_BSTAMP(i) do { } while (0)
+#endif
+#ifndef NBK_BF32_WAVES
+#define NBK_BF32_WAVES 5
+#endif
 template <int S>
-__global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
+__global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                    uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                                                    unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
                                                    unsigned long long cap, const float* __restrict__ tab) {
@@ -1904,7 +2033,8 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     const int nq = m.n_q;
     const int W = m.n_wshapes;
     double* lds_raw = lds;
-    const int qrows = (WAVE * nq * 8 >= BQ_CAP * 4) ? nq : (BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+    const int qrows = f32_qrows(nq, S);
+    const int qcap = qrows * (WAVE * 2);                                          // queue entries the slab holds
     float* lds_fr = reinterpret_cast<float*>(lds_raw + WAVE * qrows);             // saved frames [12*slots][64] float
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
     // launch-uniform tables (k_prepare_f32): scalar loads
@@ -1915,6 +2045,10 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     const float up = 1.0f + 2.4e-7f;
     const int64_t Beff = effective_batch(es, B);
     if (base >= Beff) return;               // edge mode: the launch covers the scratch's capacity, this block lies beyond the samples
+#ifdef NBK_BF32_STAMP
+    unsigned long long bstamp[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    NBK_BSTAMP(0);
     const int rows_i = (int)((Beff - base) < WAVE ? (Beff - base) : WAVE);
     if (es.map != nullptr) {
         if (lane < rows_i) {
@@ -1930,6 +2064,9 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     } else {
         const int total = rows_i * nq;
         const double* src = q + base * nq;
+#if defined(NBK_BF32_ABL) && NBK_BF32_ABL == 3      // timing experiment: no global read of q
+        if (true) { for (int i = lane; i < WAVE * nq; i += WAVE) lds_raw[i] = 0.001 * (double)(i + (int)blockIdx.x); } else
+#endif
         if (rows_i == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
             const double2* s2 = reinterpret_cast<const double2*>(src);
             double2* d2 = reinterpret_cast<double2*>(lds_raw);
@@ -1941,11 +2078,79 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     }
     __syncthreads();
     const bool active = lane < rows_i;
+    NBK_BSTAMP(1);
     bool hit = row_nonfinite(lds_raw + lane * nq, nq, 1);        // non-finite joint values: colliding, nothing queued
     // ---- sweep in float32: centres into registers ---------------------------------------------------------------------------
-    float cx[S], cy[S], cz[S];
+    // (one register tuple per coordinate: consecutive shapes are aligned register pairs, so the robot-robot slots below run two at a
+    // time on v_pk_add_f32 / v_pk_fma_f32, and the chain sweep writes centre `s` with a run-time s through VGPR indexing)
+    float cxa[S], cya[S], cza[S];
+#define cx(i_) cxa[i_]
+#define cy(i_) cya[i_]
+#define cz(i_) cza[i_]
+#define cx2v(i_) V2f{cxa[2 * (i_)], cxa[2 * (i_) + 1]}
+#define cy2v(i_) V2f{cya[2 * (i_)], cya[2 * (i_) + 1]}
+#define cz2v(i_) V2f{cza[2 * (i_)], cza[2 * (i_) + 1]}
     float rmax = m.f_reach, qabs = 0.0f;
-    {
+#pragma unroll
+    for (int i = 0; i < S; ++i) { cxa[i] = 0.0f; cya[i] = 0.0f; cza[i] = 0.0f; }
+    if (m.f_chain) {
+        // ---- serial chains of at most 8 joints (every arm): the joint loop is unrolled at COMPILE time, so every per-joint table sits
+        // at a static offset (scalar loads the compiler issues early, no dependent load -> wait -> branch chains, no address
+        // arithmetic), the q values of all joints are read up front, and the shapes of a frame are a run-time loop that writes
+        // centre `s` through VGPR indexing (s_set_gpr_idx_on); the shapes' local offsets sit in the lanes of one register and are
+        // broadcast with v_readlane.  The loop-per-shape form below spent half its instructions on scalar bookkeeping.
+        const float* ftb = m.f_tab;
+        const int nshape3 = 3 * m.n_rshapes;
+        const int tlv = lane < nshape3 ? __builtin_bit_cast(int, ftb[m.f_tl + lane]) : 0;
+        const int* jb = m.joint_shape_begin;
+        const int J = m.n_joints;
+        // joint kind | q column << 8 of all eight joint slots in one scalar load (slots beyond the robot's joints hold 0), then the
+        // eight q values in eight independent LDS reads -- no load -> wait -> read -> wait chain per joint
+        struct alignas(32) Meta8 { unsigned v[8]; };
+        const Meta8 mt = *reinterpret_cast<const Meta8*>(ftb + m.f_meta);
+        double qd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) qd[k] = lds_raw[lane * nq + (int)(mt.v[k] >> 8)];
+        float qv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { qv[k] = k < J ? (float)qd[k] : 0.0f; qabs += __builtin_fabsf(qv[k]); }
+        // the z coordinates travel through the (by now dead) q slab: the compiler keeps only two of the three centre arrays in
+        // registers under run-time indexing, the third would live in scratch for the rest of the kernel
+        __syncthreads();
+        float* lds_cz = reinterpret_cast<float*>(lds_raw);
+        XfP T;
+        {
+            const float* bp = ftb + m.f_base;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { T.Rc[k] = V2f{bp[k], bp[4 + k]}; T.R2[k] = bp[8 + k]; }
+            T.tc = V2f{bp[3], bp[7]}; T.t2 = bp[11];
+        }
+#define NBK_CHAIN_SHAPES(s0_, s1_)                                                                                              \
+        for (int sh_ = (s0_); sh_ < (s1_); ++sh_) {                                                                             \
+            const float tl0_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tlv, 3 * sh_));                              \
+            const float tl1_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tlv, 3 * sh_ + 1));                          \
+            const float tl2_ = __builtin_bit_cast(float, __builtin_amdgcn_readlane(tlv, 3 * sh_ + 2));                          \
+            const V2f cp_ = fma2(T.Rc[2], splat2(tl2_), fma2(T.Rc[1], splat2(tl1_), fma2(T.Rc[0], splat2(tl0_), T.tc)));        \
+            const float c2_ = __builtin_fmaf(T.R2[2], tl2_, __builtin_fmaf(T.R2[1], tl1_, __builtin_fmaf(T.R2[0], tl0_, T.t2))); \
+            cxa[sh_] = cp_.x; cya[sh_] = cp_.y; lds_cz[sh_ * WAVE + lane] = c2_;                                                 \
+            rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(__builtin_fabsf(cp_.x), __builtin_fmaxf(__builtin_fabsf(cp_.y), __builtin_fabsf(c2_)))); \
+        }
+        NBK_CHAIN_SHAPES(jb[0], jb[1])
+        // the constants of joint k + 1 are loaded (unconditionally: the table has a spare entry) before joint k is applied
+        JPk jcur = *reinterpret_cast<const JPk*>(ftb + m.f_pk);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const JPk jnxt = *reinterpret_cast<const JPk*>(ftb + m.f_pk + 20 * (k + 1 < 8 ? k + 1 : 7));
+            if (k < J) {
+                joint_apply_p(m, k, (int)(mt.v[k] & 255u), jcur, T, qv[k], T);
+                NBK_CHAIN_SHAPES(jb[k + 1], jb[k + 2])
+            }
+            jcur = jnxt;
+        }
+#undef NBK_CHAIN_SHAPES
+#pragma unroll
+        for (int i = 0; i < S; ++i) cza[i] = i < m.n_rshapes ? lds_cz[i * WAVE + lane] : 0.0f;
+    } else {
         XfF bpose;
         const float* bp = m.f_tab + m.f_base;
 #pragma unroll
@@ -1954,7 +2159,6 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
         int kcur = -1;
 #pragma unroll
         for (int sidx = 0; sidx < S; ++sidx) {
-            cx[sidx] = 0.0f; cy[sidx] = 0.0f; cz[sidx] = 0.0f;
             if (sidx < m.n_rshapes) {
                 const int f = m.rs_frame[sidx];
                 while (kcur < f) {
@@ -1986,7 +2190,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 float c[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) c[i] = __builtin_fmaf(F.R[3 * i + 2], tl[2], __builtin_fmaf(F.R[3 * i + 1], tl[1], __builtin_fmaf(F.R[3 * i], tl[0], F.t[i])));
-                cx[sidx] = c[0]; cy[sidx] = c[1]; cz[sidx] = c[2];
+                cx(sidx) = c[0]; cy(sidx) = c[1]; cz(sidx) = c[2];
                 rmax = __builtin_fmaxf(rmax, __builtin_fmaxf(__builtin_fabsf(c[0]), __builtin_fmaxf(__builtin_fabsf(c[1]), __builtin_fabsf(c[2]))));
             }
         }
@@ -2002,13 +2206,27 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     // stops that row and the later ones (the earlier rows' items stay: 0.097 instead of 0.088 items per configuration).
     int qn = 0;
     const int n_reach = *ft.n_reach;
+#if defined(NBK_BF32_ABL) && (NBK_BF32_ABL == 1 || NBK_BF32_ABL == 3)      // timing experiment (tools/build_variant.sh): sweep only, no pair stage
+    {
+        float acc = e2;
+#pragma unroll
+        for (int i = 0; i < S; ++i) acc += cx(i) + cy(i) + cz(i);
+        const unsigned long long word = __builtin_amdgcn_ballot_w64((hit || acc == 12345.0f) && active);
+        if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
+        return;
+    }
+#endif
     // ---- fast pair stage: every lane of the wave is within the static slack bound (always, for revolute robots with |q| sums below
     // 64 rad), so every threshold is a scalar that k_prepare_f32 has squared already: a slot costs the squared centre distance and
     // two compares.  The compare results stay lane masks in scalar registers -- no per-lane survivor bits -- and are queued slot by
     // slot (a pair at a time) after the world shape's / the row's certified hits are known.
+    NBK_BSTAMP(2);
     if (__builtin_amdgcn_ballot_w64(!(e2 <= m.f_e2max)) == 0ull) {
-        const float* tab_rkey2 = ft.rkey2;
+        const float* tab_rneg = ft.rneg;
+        const float* tab_rnd = ft.rnd;
         const float* tab_wkey2 = ft.wkey2;
+        // one queue append: lanes with `cond_` get consecutive slots behind the pending items.  No "nearly full" test here:
+        // NBK_ROOM makes room for a whole row of slots before the row's appends start
 #define NBK_ENQUEUE(cond_, pidx_)                                                                                               \
         {                                                                                                                       \
             const bool c_ = (cond_);                                                                                            \
@@ -2019,13 +2237,22 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                     lds_queue[pos_] = ((unsigned)(pidx_) << 6) | (unsigned)lane;                                                \
                 }                                                                                                               \
                 qn += __builtin_popcountll(cm_);                                                                                \
-                if (qn > BQ_CAP - WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }   \
             }                                                                                                                   \
         }
+#define NBK_ROOM(slots_)                                                                                                        \
+        if (qn > qcap - (slots_) * WAVE) { flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf); qn = 0; }
+#if defined(NBK_BF32_ABL) && NBK_BF32_ABL == 5
+        for (int wi = 0; wi < (e2 == 12345.0f ? n_reach : 0); ++wi) {
+#else
         for (int wi = 0; wi < n_reach; ++wi) {
+#endif
             const int w = ft.wlist[wi];
             const float* wc = m.f_tab + m.f_wc + 18 * w;
             const int wk = m.ws_kind[w];
+            // this world shape's rows of the slot tables: one 64-byte scalar load each
+            const Row16f wkey2r = *reinterpret_cast<const Row16f*>(tab_wkey2 + w * 16);
+            const Row16f wcertr = *reinterpret_cast<const Row16f*>(tab_wcert + w * 16);
+            const Row16f wkeyr = *reinterpret_cast<const Row16f*>(tab_wkey + w * 16);
             bool c[S];
             bool ch = false;
 #pragma unroll
@@ -2034,50 +2261,68 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
 #pragma unroll
                 for (int a = 0; a < S; ++a) {
                     if (a < m.n_rshapes && tab_wp[w * 16 + a] >= 0) {
-                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                        const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
                         const float hc = __builtin_fmaf(dz, wc[11], __builtin_fmaf(dy, wc[10], dx * wc[9]));
-                        c[a] = hc < tab_wkey2[w * 16 + a];
-                        ch = ch || (hc < tab_wcert[w * 16 + a]);
+                        c[a] = hc < wkey2r.v[a];
+                        ch = ch || (hc < wcertr.v[a]);
                     }
                 }
             } else if (wk == K_BOX) {
+                // Two robot shapes (2i, 2i + 1) per trip against the box, no branch and no lane mask per slot: the centre's squared distance
+                // dd to the box centre and ex2 to the (core) box itself -- ex_j = |d . axis_j| - h_j, clamped at 0, squared and summed --
+                // and mx = max_j ex_j (< 0: the centre is inside).  Every verdict is the sign of a difference with a per-slot scalar
+                // (k_prepare_f32: all thresholds carry the STATIC slack bound, which this stage's lanes stay within):
+                //   candidate  dd < wkey2 (bounding spheres) and ex2 < cull2 (closer to the box than tc+ + rho + slack)
+                //   certain hit, outside  candidate, ex2 > 0 and ex2 < cin (inside the ball inscribed in the shape, slack taken off)
+                //   certain hit, inside   candidate, mx < 0, mx < -g (deeper than -tc + slack) and dd < kin
+                const float* wb = ft.wbx + w * 96;
+                int cwv[S];
+                int acc_c = 0, acc_h = 0;
 #pragma unroll
-                for (int a = 0; a < S; ++a) {
-                    if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
-                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
-                        const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        bool cand = dd < tab_wkey2[w * 16 + a];
-                        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {         // exact-box midphase, as in the general stage below
-                            const float rs = tab_wkey[w * 16 + a], tc = tab_wtc[w * 16 + a], rho = tab_rho[a];
-                            float ex2 = 0.0f, g = 3.4e38f;
-                            bool inside = true;
+                for (int i = 0; i < S / 2; ++i) {
+                    const V2f dx = cx2v(i) - splat2(wc[0]), dy = cy2v(i) - splat2(wc[1]), dz = cz2v(i) - splat2(wc[2]);
+                    const V2f dd = fma2(dz, dz, fma2(dy, dy, dx * dx));
+                    V2f ex[3], ex2 = V2f{0.0f, 0.0f};
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const float axj = __builtin_fabsf(__builtin_fmaf(dz, wc[5 + 3 * j], __builtin_fmaf(dy, wc[4 + 3 * j], dx * wc[3 + 3 * j])));
-                                const float exj = axj - wc[12 + j];
-                                if (exj > 0.0f) { inside = false; ex2 = __builtin_fmaf(exj, exj, ex2); }
-                                g = __builtin_fminf(g, wc[12 + j] - axj);
-                            }
-                            if (!inside) {
-                                const float rr = ((tc > 0.0f ? tc : 0.0f) + rho) + e2;   // tc < 0: disjoint is enough (device-only cull)
-                                if (ex2 >= rr * rr * up) cand = false;
-                                if (cand && ex2 < tab_wcin[w * 16 + a]) ch = true;
-                            } else if (cand && g > -tc + e2 && rs > e2 && dd * up < (rs - e2) * (rs - e2)) {
-                                ch = true;
-                            }
-                        }
-                        c[a] = cand;
+                    for (int j = 0; j < 3; ++j) {
+                        const V2f pj = fma2(dz, splat2(wc[5 + 3 * j]), fma2(dy, splat2(wc[4 + 3 * j]), dx * splat2(wc[3 + 3 * j])));
+                        ex[j] = V2f{__builtin_fabsf(pj.x) - wc[12 + j], __builtin_fabsf(pj.y) - wc[12 + j]};
+                        const V2f cl = V2f{__builtin_fmaxf(ex[j].x, 0.0f), __builtin_fmaxf(ex[j].y, 0.0f)};
+                        ex2 = fma2(cl, cl, ex2);
                     }
+                    const V2f mx = V2f{__builtin_fmaxf(ex[0].x, __builtin_fmaxf(ex[1].x, ex[2].x)), __builtin_fmaxf(ex[0].y, __builtin_fmaxf(ex[1].y, ex[2].y))};
+                    const float* tb = wb + 12 * i;
+                    const V2i s1 = __builtin_bit_cast(V2i, dd - V2f{tb[0], tb[1]});
+                    const V2i s2 = __builtin_bit_cast(V2i, ex2 - V2f{tb[2], tb[3]});
+                    const V2i s3 = __builtin_bit_cast(V2i, ex2 - V2f{tb[4], tb[5]});
+                    const V2i s4 = __builtin_bit_cast(V2i, dd - V2f{tb[6], tb[7]});
+                    const V2i s5 = __builtin_bit_cast(V2i, mx + V2f{tb[8], tb[9]});
+                    const V2i nz = __builtin_bit_cast(V2i, V2f{0.0f, 0.0f} - ex2);         // sign set <=> ex2 > 0 (a true subtraction: +0 - +0 = +0)
+                    const V2i mi = __builtin_bit_cast(V2i, mx);
+                    const V2i cand = s1 & s2;
+                    const V2i certh = cand & ((s3 & nz) | (mi & s5 & s4));
+                    cwv[2 * i] = cand.x; cwv[2 * i + 1] = cand.y;
+                    acc_c |= cand.x | cand.y;
+                    acc_h |= certh.x | certh.y;
                 }
+                hit = hit || (acc_h < 0);
+                const bool live = active && !hit && !(NBK_DBG(m) & 4);
+                if (__builtin_amdgcn_ballot_w64(acc_c < 0 && live) != 0ull) {
+                    NBK_ROOM(S)
+#pragma unroll
+                    for (int a = 0; a < S; ++a)
+                        if (a < m.n_rshapes) NBK_ENQUEUE(cwv[a] < 0 && live, tab_wp[w * 16 + a]);
+                }
+                continue;
             } else if (wk == K_HULL) {
                 const float* ob = m.f_tab + m.f_wobb + 6 * w;            // the hull's local bounding box
 #pragma unroll
                 for (int a = 0; a < S; ++a) {
-                    if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
-                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    if (a < m.n_rshapes && wkeyr.v[a] >= 0.0f) {
+                        const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
                         const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        bool cand = dd < tab_wkey2[w * 16 + a];
-                        ch = ch || (dd < tab_wcert[w * 16 + a]);
+                        bool cand = dd < wkey2r.v[a];
+                        ch = ch || (dd < wcertr.v[a]);
                         if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {     // centre against the hull's box: only a cull
                             const float tc = tab_wtc[w * 16 + a], rho = tab_rho[a];
                             float ex2 = 0.0f;
@@ -2096,11 +2341,11 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
             } else {
 #pragma unroll
                 for (int a = 0; a < S; ++a) {
-                    if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
-                        const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    if (a < m.n_rshapes && wkeyr.v[a] >= 0.0f) {
+                        const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
                         const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        c[a] = dd < tab_wkey2[w * 16 + a];
-                        ch = ch || (dd < tab_wcert[w * 16 + a]);
+                        c[a] = dd < wkey2r.v[a];
+                        ch = ch || (dd < wcertr.v[a]);
                     }
                 }
             }
@@ -2110,39 +2355,68 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
 #pragma unroll
             for (int a = 0; a < S; ++a) anyc = anyc || c[a];
             if (__builtin_amdgcn_ballot_w64(anyc && live) != 0ull) {          // one branch per world shape; most have no candidate
+                NBK_ROOM(S)
 #pragma unroll
                 for (int a = 0; a < S; ++a)
                     if (a < m.n_rshapes) NBK_ENQUEUE(c[a] && live, tab_wp[w * 16 + a]);
             }
         }
+        NBK_BSTAMP(3);
         if (m.bq_count[1] > 0) {
 #pragma unroll
             for (int a = 0; a < S - 1; ++a) {
-                bool c[S];
-                bool ch = false;
+                // row a of the slot table: one 64-byte scalar load.  Two slots (b, b + 1) per trip: e = |ca - cb|^2 - k2 as an fma
+                // chain that starts from -k2; a candidate is a NEGATIVE e, so the row's verdict is the sign bit of one OR-accumulator --
+                // no compare, no lane mask, no scalar instruction per slot.  Slots b <= a of the first pair and slots that are not
+                // pairs hold +1: never negative.  Only a row with a candidate (one branch per row) looks further: f = e + (k2 - cert)
+                // is negative for a certified hit (a certified pair is a candidate: cert < k2), then the candidates of the lanes that
+                // are still undecided are queued from the e's kept in registers.
+                const Row16f nk = *reinterpret_cast<const Row16f*>(tab_rneg + a * 16);
+                const V2f ax2 = V2f{cx(a), cx(a)}, ay2 = V2f{cy(a), cy(a)}, az2 = V2f{cz(a), cz(a)};
+                V2f ev[S / 2];
+                int acc_e = 0;
 #pragma unroll
-                for (int b = a + 1; b < S; ++b) {
-                    const float dx = cx[a] - cx[b], dy = cy[a] - cy[b], dz = cz[a] - cz[b];
-                    const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                    c[b] = dd < tab_rkey2[a * 16 + b];
-                    ch = ch || (dd < tab_rcert[a * 16 + b]);
+                for (int i = (a + 1) / 2; i < S / 2; ++i) {
+                    ev[i] = slot_e2(ax2 - cx2v(i), ay2 - cy2v(i), az2 - cz2v(i), V2f{nk.v[2 * i], nk.v[2 * i + 1]});
+                    // (bit-cast the PAIR, then OR its halves: `bit_cast<int>(e.x) | bit_cast<int>(e.y)` under a sign test loses the
+                    // second element in this compiler -- ROCm 7.2 clang folds it to element 0 already in the IR)
+                    const V2i ei = __builtin_bit_cast(V2i, ev[i]);
+                    acc_e |= ei.x | ei.y;
                 }
-                hit = hit || ch;
-                const bool live = active && !hit;
-                bool anyc = false;
+#if defined(NBK_BF32_ABL) && NBK_BF32_ABL == 4
+                if (__builtin_amdgcn_ballot_w64(acc_e < 0 && active && !hit && e2 == 12345.0f) != 0ull) {
+#else
+                if (__builtin_amdgcn_ballot_w64(acc_e < 0 && active && !hit) != 0ull) {
+#endif
+                    const Row16f nd = *reinterpret_cast<const Row16f*>(tab_rnd + a * 16);
+                    int acc_f = 0;
 #pragma unroll
-                for (int b = a + 1; b < S; ++b) anyc = anyc || c[b];
-                if (__builtin_amdgcn_ballot_w64(anyc && live) != 0ull) {      // one branch per row
+                    for (int i = (a + 1) / 2; i < S / 2; ++i) {
+                        const V2i fi = __builtin_bit_cast(V2i, ev[i] + V2f{nd.v[2 * i], nd.v[2 * i + 1]});
+                        acc_f |= fi.x | fi.y;
+                    }
+                    hit = hit || (acc_f < 0);
+                    const bool live = active && !hit;
+                    NBK_ROOM(S)
 #pragma unroll
-                    for (int b = a + 1; b < S; ++b) NBK_ENQUEUE(c[b] && live, ft.rp[a * 16 + b]);
+                    for (int b = a + 1; b < S; ++b) {
+                        const V2i ei = __builtin_bit_cast(V2i, ev[b / 2]);
+                        NBK_ENQUEUE(((b % 2) ? ei.y : ei.x) < 0 && live, ft.rp[a * 16 + b]);
+                    }
                 }
             }
         }
 #undef NBK_ENQUEUE
+#undef NBK_ROOM
+        NBK_BSTAMP(4);
         if (qn > 0) flush_items(m, lds_queue, qn, base, q_count, q_items, cap, lane, es.ovf);
         const unsigned long long word = __builtin_amdgcn_ballot_w64(hit && active);
         if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
         if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
+#ifdef NBK_BF32_STAMP
+        NBK_BSTAMP(5);
+        if (lane == 0) { unsigned long long* pr_ = g_broad_prof + 8 * (blockIdx.x & 16383u); for (int e_ = 0; e_ < 5; ++e_) pr_[e_] += bstamp[e_ + 1] - bstamp[e_]; pr_[7] += 1ull; }
+#endif
         return;
     }
     // ---- general pair stage (some lane's slack exceeds the static bound: prismatic travel, huge joint values) ----------------------
@@ -2159,7 +2433,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 if (a < m.n_rshapes && tab_wp[w * 16 + a] >= 0) {          // uniform: not a pair, or out of reach for good
                     const float key = tab_wkey[w * 16 + a];
                     const float rhoA = tab_rho[a];
-                    const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
                     const float hc = __builtin_fmaf(dz, wc[11], __builtin_fmaf(dy, wc[10], dx * wc[9]));
                     const bool cand = (tab_wp[w * 16 + a] >= 0) && !((hc - rhoA) >= key + e2);
                     bits |= cand ? (1ull << a) : 0ull;
@@ -2173,7 +2447,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                     const float rs = tab_wkey[w * 16 + a];
                     const float tc = tab_wtc[w * 16 + a];
                     const float rho = tab_rho[a];
-                    const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
                     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     const float r = rs + e2;
                     bool cand = rs >= 0.0f && dd < r * r * up;
@@ -2210,7 +2484,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
                 if (a < m.n_rshapes && tab_wkey[w * 16 + a] >= 0.0f) {
                     const float rs = tab_wkey[w * 16 + a];
                     const float r = rs + e2;
-                    const float dx = cx[a] - wc[0], dy = cy[a] - wc[1], dz = cz[a] - wc[2];
+                    const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
                     const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                     bool cand = rs >= 0.0f && dd < r * r * up;
                     if (is_hull && __builtin_amdgcn_ballot_w64(cand) != 0ull) {
@@ -2255,7 +2529,7 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
             for (int b = a + 1; b < S; ++b) {
                 const float rs = tab_rkey[a * 16 + b];
                 const float r = rs + e2;
-                const float dx = cx[a] - cx[b], dy = cy[a] - cy[b], dz = cz[a] - cz[b];
+                const float dx = cx(a) - cx(b), dy = cy(a) - cy(b), dz = cz(a) - cz(b);
                 const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
                 bits |= (rs >= 0.0f && dd < r * r * up) ? (1ull << b) : 0ull;
                 certh = certh || (dd < tab_rcert[a * 16 + b]);
@@ -2283,6 +2557,12 @@ __global__ __launch_bounds__(64, 6) void k_broad_f32(DevModel m, EdgeSrc es, con
     if (mask_bits != nullptr && lane == 0) mask_bits[blockIdx.x] = word;
     if (mask_bytes != nullptr && active) mask_bytes[base + lane] = hit ? 1 : 0;
 }
+#undef cx
+#undef cy
+#undef cz
+#undef cx2v
+#undef cy2v
+#undef cz2v
 
 // core of shape `ref` (robot: from the replayed frame T; world: table).  Everything here is per lane.
 NBK_DEV void build_core(const DevModel& m, int ref, const Xf& T, Core& o) {
@@ -3360,10 +3640,10 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     for (double& v : jtrans) v += 0.0;
     std::vector<int> joint_kind(J > 0 ? J : 1, JK_GENERIC);
     for (int k = 0; k < J; ++k) {
-        const double* M = &jrot[27 * (size_t)k];
+        const double* Mk = &jrot[27 * (size_t)k];
         if (d->joint_type[k] == NBK_PRISMATIC) {
             bool zero = true;
-            for (int e = 9; e < 27; ++e) zero = zero && M[e] == 0.0;
+            for (int e = 9; e < 27; ++e) zero = zero && Mk[e] == 0.0;
             if (!zero) { delete M; snprintf(g_err, sizeof(g_err), "prismatic joint %d: M1 / M2 of joint_rot must be zero", k); return NBK_ERR_INVALID; }
             joint_kind[k] = JK_PRISMATIC;
             continue;
@@ -3372,7 +3652,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
             const int u = (kz + 1) % 3, v = (kz + 2) % 3;
             bool ok = d->joint_slide[3 * k] == 0.0 && d->joint_slide[3 * k + 1] == 0.0 && d->joint_slide[3 * k + 2] == 0.0;
             for (int r = 0; r < 3; ++r)
-                ok = ok && M[9 + 3 * r + kz] == 0.0 && M[18 + 3 * r + kz] == 0.0 && M[3 * r + u] == 0.0 && M[3 * r + v] == 0.0;
+                ok = ok && Mk[9 + 3 * r + kz] == 0.0 && Mk[18 + 3 * r + kz] == 0.0 && Mk[3 * r + u] == 0.0 && Mk[3 * r + v] == 0.0;
             if (ok) { joint_kind[k] = kz; break; }
         }
     }
@@ -3440,7 +3720,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         for (int j = 0; j < 3; ++j) { hull_obb[6 * h + j] = 0.5 * (lo[j] + hi[j]); hull_obb[6 * h + 3 + j] = 0.5 * (hi[j] - lo[j]) * (1.0 + 1e-12) + 1e-300; }
     }
     std::vector<float> ftab;
-    int f_trans, f_slide, f_base, f_tl, f_wc, f_wobb = 0;
+    int f_trans, f_slide, f_base, f_tl, f_wc, f_wobb = 0, f_pk = 0, f_meta = 0, f_chain = 0;
     double reach = 0.0;
     {
         for (int k = 0; k < J; ++k) for (int e = 0; e < 27; ++e) ftab.push_back((float)d->joint_rot[27 * k + e]);
@@ -3480,6 +3760,30 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
                 const double v = ws_hull[w] >= 0 ? hull_obb[6 * (size_t)ws_hull[w] + e] : 0.0;
                 ftab.push_back(e < 3 ? (float)v : (float)v * (1.0f + 2.4e-7f));          // half extents rounded up
             }
+        // per-joint constants of the packed sweep (k_broad_f32): for a joint about coordinate axis KZ of its frame (U, V = the two
+        // other axes) the pairs (M2[r][U], M2[r][V]) and (M1[r][U], M1[r][V]), r = 0..2, column KZ of M0, the offset translation
+        while (ftab.size() % 4 != 0) ftab.push_back(0.0f);
+        f_pk = (int)ftab.size();
+        for (int k = 0; k < (J > 8 ? J : 8); ++k) {
+            if (k >= J) { for (int e = 0; e < 20; ++e) ftab.push_back(0.0f); continue; }      // (the chain sweep prefetches entry k + 1 <= 7)
+            const double* M = d->joint_rot + 27 * (size_t)k;
+            const int kz = joint_kind[k] <= 2 ? joint_kind[k] : 0;
+            const int u = (kz + 1) % 3, v = (kz + 2) % 3;
+            for (int r = 0; r < 3; ++r) { ftab.push_back((float)M[18 + 3 * r + u]); ftab.push_back((float)M[18 + 3 * r + v]); }
+            for (int r = 0; r < 3; ++r) { ftab.push_back((float)M[9 + 3 * r + u]); ftab.push_back((float)M[9 + 3 * r + v]); }
+            for (int r = 0; r < 3; ++r) ftab.push_back((float)M[3 * r + kz]);
+            ftab.push_back(0.0f);
+            for (int e = 0; e < 3; ++e) ftab.push_back((float)d->joint_trans[3 * k + e]);
+            ftab.push_back(0.0f);
+        }
+        f_meta = (int)ftab.size();
+        for (int k = 0; k < 8; ++k) {
+            const unsigned v = k < J ? ((unsigned)joint_kind[k] | ((unsigned)d->joint_qidx[k] << 8)) : 0u;
+            float fv; memcpy(&fv, &v, 4);
+            ftab.push_back(fv);
+        }
+        f_chain = (J >= 1 && J <= 8 && S <= 16) ? 1 : 0;
+        for (int k = 0; k < J && f_chain; ++k) if (load[k] != (k == 0 ? -1 : -2) || save[k] != -1) f_chain = 0;
         if (ftab.empty()) ftab.push_back(0.0f);
     }
     o.ft = B.add(ftab.data(), sizeof(float) * ftab.size());
@@ -3580,7 +3884,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.vp_cls = reinterpret_cast<const int*>(base + o.vcl);
     for (int c = 0; c < 4; ++c) { m.cls_base[c] = cls_base[c]; m.cls_groups[c] = cls_groups[c] > 0 ? cls_groups[c] : 1; }
     m.f_tab = reinterpret_cast<const float*>(base + o.ft);
-    m.f_trans = f_trans; m.f_slide = f_slide; m.f_base = f_base; m.f_tl = f_tl; m.f_wc = f_wc; m.f_wobb = f_wobb;
+    m.f_trans = f_trans; m.f_slide = f_slide; m.f_base = f_base; m.f_tl = f_tl; m.f_wc = f_wc; m.f_wobb = f_wobb; m.f_pk = f_pk; m.f_meta = f_meta; m.f_chain = f_chain;
     // relative slack: 50 x the float32 error bound (joints + 2) * 16 ulp of a chain sweep; the kernel multiplies it by the
     // larger of the static reach and the configuration's own largest coordinate (prismatic travel is unbounded here)
     {
@@ -3648,6 +3952,22 @@ extern "C" int32_t nbk_debug_narrow_profile(unsigned long long* out, int32_t res
     if (out != nullptr) NBK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(nbk::g_narrow_prof), sizeof(unsigned long long) * 16));
     if (reset) { unsigned long long z[16] = {0}; z[13] = ~0ull; NBK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nbk::g_narrow_prof), z, sizeof(z))); }
     return NBK_OK;
+}
+
+// diagnostic (not part of include/nbk.h): cycles per phase of k_broad_f32 (builds with -DNBK_BF32_STAMP), out[8]
+extern "C" int32_t nbk_debug_broad_profile(unsigned long long* out, int32_t reset) {
+#ifdef NBK_BF32_STAMP
+    static std::vector<unsigned long long> h(16384 * 8);
+    if (out != nullptr) {
+        NBK_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(nbk::g_broad_prof), sizeof(unsigned long long) * h.size()));
+        for (int e = 0; e < 8; ++e) { out[e] = 0; for (size_t b = 0; b < 16384; ++b) out[e] += h[8 * b + e]; }
+    }
+    if (reset) { std::fill(h.begin(), h.end(), 0ull); NBK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(nbk::g_broad_prof), h.data(), sizeof(unsigned long long) * h.size())); }
+    return NBK_OK;
+#else
+    (void)out; (void)reset;
+    return NBK_ERR_UNSUPPORTED;
+#endif
 }
 
 int32_t nbk_model_num_pairs(const nbk_model* m) { return m ? m->n_pairs : NBK_ERR_INVALID; }
@@ -3860,7 +4180,7 @@ static const size_t WS_FLAGS = (size_t)(TILE_MAX / WAVE);       // one overflow 
 static const size_t WS_COUNTER_SET = NSUB * CNT_STRIDE * 8;    // NSUB counters, one cache line each
 static const size_t WS_COUNTERS = 2 * WS_COUNTER_SET;          // two sets (see StreamWs::epoch)
 static inline size_t ws_tables(const nbk_model* m) {           // counters | per-call float32 broadphase tables
-    return (WS_COUNTERS + 4 * (4 * 256 + 128 + 6 * (size_t)m->d.n_wshapes * 16 + 32 + (size_t)m->d.n_wshapes + 16) + 255) & ~size_t(255);
+    return (WS_COUNTERS + 4 * (5 * 256 + 128 + 6 * (size_t)m->d.n_wshapes * 16 + 32 + (size_t)m->d.n_wshapes + 16 + 96 * (size_t)m->d.n_wshapes + 16) + 255) & ~size_t(255);
 }
 static inline size_t ws_header(const nbk_model* m) { return ws_tables(m) + WS_FLAGS; }      // ... | overflow marks | items follow
 
@@ -4035,7 +4355,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         uint8_t* my = mask_bytes ? mask_bytes + b0 : nullptr;
         float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
-        const size_t qrows_f = ((size_t)WAVE * m->d.n_q * 8 >= (size_t)BQ_CAP * 4) ? (size_t)m->d.n_q : ((size_t)BQ_CAP * 4 + WAVE * 8 - 1) / (WAVE * 8);
+        const size_t qrows_f = (size_t)f32_qrows(m->d.n_q, S <= 8 ? 8 : (S <= 12 ? 12 : 16));
         const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16;
         unsigned long long* count_next = nullptr;
         if (use_reg && f32) {
@@ -4145,6 +4465,10 @@ int32_t nbk_validity_batch_ws(const nbk_model* m, const double* q, int64_t B, do
     if (B == 0) return NBK_OK;
     hipStream_t st = (hipStream_t)stream;
     const int64_t need = nbk_validity_workspace_bytes(m, B);
+    if (workspace != nullptr && (reinterpret_cast<uintptr_t>(workspace) & 63u) != 0) {
+        snprintf(g_err, sizeof(g_err), "workspace must be 64-byte aligned");
+        return NBK_ERR_INVALID;
+    }
     if (need == 0 || workspace == nullptr || workspace_bytes < need) {
         if (need != 0 && workspace != nullptr) return NBK_ERR_INVALID;       // a workspace was given but is too small
         if (!m->parked_ok) return need != 0 ? NBK_ERR_INVALID : NBK_ERR_UNSUPPORTED;   // this robot needs the workspace path
