@@ -25,6 +25,8 @@ HBM).  Beside it, all timed with HIP events on the launch stream, median and min
                         on the primitive scene and on the mesh scene (compound-mesh collision shapes)
   config1_plumbing      config 1: tool_frame FK of 1024 q, CPU oracle rate beside one device call
   config4_shard         one GPU's share of config 4's 1e7 batch (1.25e6 q)
+  config4_strong        N > 1 only, no flag needed: BASELINE config 4 itself -- 1e7 q split over the ranks, gathered mask checked
+                        against the oracle on rank 0, ms per step with a serial and with an overlapped all-gather
   two_streams           the headline steps issued alternately on two HIP streams (independent batches): throughput with the
                         narrowphase of one step under the broadphase of the next
   fk_roofline, fk_all_links_roofline, jacobian_roofline   the HBM-bound kernels of the path
@@ -173,6 +175,68 @@ def main():
     kern_ms = kern["mean_ms"]
     last_q_host = q_host if (args.steps - 1) % N_ROTATE == 0 else sample_q(chain, B, seed=1 + rank + 1000 * ((args.steps - 1) % N_ROTATE))
 
+    # ---- BASELINE config 4, whenever N > 1 (no flag needed): a 1e7-q batch strong-scaled over the ranks, packed masks all-gathered ---------
+    config4 = None
+    if world > 1 and not strong:
+        G4 = 10_000_000
+        lo4, hi4 = shard_bounds(G4, world, rank)
+        B4 = hi4 - lo4
+        w4 = shard_words(G4, world)
+        q4 = torch.from_numpy(sample_q(chain, max(B4, 1), seed=40 + rank)).cuda()[:B4]
+        gath4 = [torch.zeros((world * w4,), dtype=torch.int64, device="cuda") for _ in range(2)]
+        pad4 = torch.zeros((w4,), dtype=torch.int64, device="cuda")
+
+        def step4(i, overlapped):
+            wd = dev.validity(q4, 0.0, packed=True) if B4 > 0 else pad4[:0]
+            if wd.numel() != w4:
+                pad4.zero_(); pad4[:wd.numel()].copy_(wd); wd = pad4
+            if overlapped and args.backend == "nccl":
+                return dist.all_gather_into_tensor(gath4[i & 1], wd.contiguous(), async_op=True)
+            allgather_mask_words(wd, gath4[i & 1])
+            return None
+
+        def run4(n, overlapped):
+            pend = [None, None]
+            torch.cuda.synchronize(); dist.barrier()
+            t_ = time.perf_counter()
+            for i in range(n):
+                if pend[i & 1] is not None:
+                    pend[i & 1].wait()
+                pend[i & 1] = step4(i, overlapped)
+            for p_ in pend:
+                if p_ is not None:
+                    p_.wait()
+            torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) / n * 1e3
+        run4(2, False)
+        ms_serial = run4(5, False)
+        ms_overlap = run4(5, True) if args.backend == "nccl" else None
+        run4(1, False)                                       # leaves the gathered mask of this batch in gath4[0]
+        config4 = {"what": "BASELINE config 4: 1e7 q strong-scaled over the ranks (shard_bounds: 64-aligned contiguous shards), one "
+                           "all_gather_into_tensor of the packed mask words per step", "global_batch": G4, "ranks": world,
+                   "batch_rank0": B4, "message_bytes_per_rank": 8 * w4, "ms_per_step_serial_gather": ms_serial,
+                   "ms_per_step_overlapped_gather": ms_overlap,
+                   "configs_per_s": G4 / ((ms_overlap or ms_serial) * 1e-3), "backend": args.backend}
+        if rank == 0:
+            # the gathered mask against the oracle on a strided slice of the GLOBAL batch (every rank's shard is re-generated here)
+            from oracle.cpu_oracle import Oracle as _O4
+            gw = gath4[0].cpu().numpy().view(np.uint64)
+            ok4, n4 = True, 0
+            for r_ in range(world):
+                lo_r, hi_r = shard_bounds(G4, world, r_)
+                if hi_r <= lo_r:
+                    continue
+                qr = sample_q(chain, hi_r - lo_r, seed=40 + r_)
+                sl4 = np.arange(0, hi_r - lo_r, 997)
+                wr = gw[r_ * w4:(r_ + 1) * w4]
+                bits_r = ((wr[:, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).astype(bool).reshape(-1)
+                ok4 = ok4 and bool(np.array_equal(bits_r[sl4], _O4(sm).validity(qr[sl4], 0.0, nthreads=8)))
+                n4 += int(sl4.size)
+            config4["gathered_mask_vs_oracle"] = ("bit-exact" if ok4 else "MISMATCH") + f" on {n4} configurations of all {world} shards"
+        del q4, gath4
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -309,6 +373,9 @@ def main():
     modes["bullet_margins" if args.sharp else "sharp"] = other
     modes["sharp" if args.sharp else "bullet_margins"]["collision_fraction"] = coll_frac
     out["modes"] = modes
+    if config4 is not None:
+        out["config4_strong"] = config4
+        parity_ok = parity_ok and "MISMATCH" not in config4.get("gathered_mask_vs_oracle", "")
     parity_ok = parity_ok and other_ok
     arm.bullet_margins = not args.sharp
     del dev_o

@@ -21,11 +21,18 @@ def collision_mask(arm, points, collision_tolerance: float = 1e-6):
     return arm.in_collision(points, collision_tolerance)
 
 
-def counter_example_bisection(arm, centre, points, num_bisections: int = 15, collision_tolerance: float = 1e-6):
+def counter_example_bisection(arm, centre, points, num_bisections: int = 15, collision_tolerance: float = 1e-6, graph: bool = False):
     """For each colliding point q: bisect [centre, q] keeping the colliding end, return the final upper ends.
 
     Same arithmetic per sample as upstream: ``midpoint = (lo + hi) / 2.0``; a colliding midpoint replaces
-    ``hi``, a free one replaces ``lo``."""
+    ``hi``, a free one replaces ``lo``.
+
+    ``points`` as a torch CUDA tensor keeps every round on the device -- midpoints, the validity launch and the interval
+    update (``torch.where`` on the returned mask) with no copy through the host -- and returns a CUDA tensor, bit-equal to the
+    NumPy form.  ``graph=True`` replays one captured round (midpoint, validity kernels, update: one graph launch instead of six)
+    from a graph kept on the Arm per (scene, M, tolerance); the first such call pays for the capture."""
+    if type(points).__module__.startswith("torch") and points.is_cuda:
+        return _bisection_on_device(arm, centre, points, num_bisections, collision_tolerance, graph)
     points = np.asarray(points, dtype=np.float64)
     lo = np.tile(np.asarray(centre, dtype=np.float64)[None], (points.shape[0], 1))
     hi = points.copy()
@@ -35,6 +42,76 @@ def counter_example_bisection(arm, centre, points, num_bisections: int = 15, col
         hi[hit] = mid[hit]
         lo[~hit] = mid[~hit]
     return hi
+
+
+class _BisectionGraph:
+    """One captured bisection round over persistent buffers (lo, hi, mid, mask) on a private stream, for one (scene, M, tolerance):
+    capturing costs more than a whole 15-round search, so the graph is kept on the Arm and replayed by later calls."""
+
+    def __init__(self, dev, M, nq, tol, device):
+        import torch
+        from numbotics_amd import _lib
+        self.dev, self.M, self.tol = dev, M, float(tol)
+        self.lo = torch.empty((M, nq), dtype=torch.float64, device=device)
+        self.hi = torch.empty_like(self.lo)
+        self.mid = torch.empty_like(self.lo)
+        self.mask = torch.empty((M,), dtype=torch.uint8, device=device)
+        self.stream = torch.cuda.Stream()
+        self._check = _lib.check
+        self.graph = None
+
+    def round(self):
+        import torch
+        torch.add(self.lo, self.hi, out=self.mid)
+        self.mid.div_(2.0)                                # (lo + hi) / 2.0, as upstream
+        self._check(self.dev._lib.nbk_validity_batch(self.dev._h, self.mid.data_ptr(), self.M, self.tol, None, self.mask.data_ptr(),
+                                                     self.dev._stream()), "nbk_validity_batch")
+        hit = self.mask.bool().unsqueeze(1)
+        torch.where(hit, self.mid, self.hi, out=self.hi)
+        torch.where(hit, self.lo, self.mid, out=self.lo)
+
+    def run(self, centre, pts, rounds):
+        import torch
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.lo.copy_(centre.expand_as(self.lo))
+            self.hi.copy_(pts)
+            if self.graph is None:
+                self.round()                              # allocates the stream's scratch: a capture cannot
+                rounds -= 1
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):     # records one round, executes nothing
+                    self.round()
+                self.graph = g
+            for _ in range(rounds):
+                self.graph.replay()
+            out = self.hi.clone()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return out
+
+
+def _bisection_on_device(arm, centre, points, num_bisections, tol, graph):
+    import torch
+    pts = points.to(torch.float64).contiguous()
+    M, nq = pts.shape
+    c = torch.as_tensor(np.asarray(centre, dtype=np.float64), device=pts.device).reshape(1, nq)
+    if M == 0 or num_bisections <= 0:
+        return pts.clone()
+    _, dev = arm._scene_device()
+    if graph:
+        cache = arm.__dict__.setdefault("_bisection_graphs", {})
+        key = (id(dev), M, float(tol), pts.device.index)
+        if key not in cache:
+            if len(cache) >= 8:
+                cache.clear()
+            cache[key] = _BisectionGraph(dev, M, nq, tol, pts.device)
+        return cache[key].run(c, pts, num_bisections)
+    state = _BisectionGraph(dev, M, nq, tol, pts.device)
+    state.lo.copy_(c.expand(M, nq))
+    state.hi.copy_(pts)
+    for _ in range(num_bisections):
+        state.round()
+    return state.hi
 
 
 def distance_and_gradient(arm, points, link, obj):

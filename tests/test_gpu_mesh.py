@@ -101,6 +101,12 @@ def test_mesh_edges_and_iris_steps(fresh_world, torch_cuda):
     assert not arm.in_collision(seed_q, 1e-6)
     hi = counter_example_bisection(arm, seed_q, pts[mask][:500], 15, 1e-6)
     assert np.asarray(arm.in_collision(hi, 1e-6)).all()
+    # M = 10 071 samples, 15 rounds, on device tensors (no host copy per round) and from one captured hipGraph: bit-equal to the host loop
+    torch = torch_cuda
+    hi_all = counter_example_bisection(arm, seed_q, pts, 15, 1e-6)
+    pts_d = torch.from_numpy(pts).cuda()
+    assert np.array_equal(counter_example_bisection(arm, seed_q, pts_d, 15, 1e-6).cpu().numpy(), hi_all)
+    assert np.array_equal(counter_example_bisection(arm, seed_q, pts_d, 15, 1e-6, graph=True).cpu().numpy(), hi_all)
 
 
 @pytest.mark.parametrize("seed", [201, 203, 204, 207, 208, 211])

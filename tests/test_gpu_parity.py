@@ -429,6 +429,13 @@ def test_iris_inner_steps(fresh_world, torch_cuda):
                 lo_i = mid
         assert np.array_equal(hi_i, hi[i])
     assert np.asarray(arm.in_collision(hi, 1e-6)).all()          # the returned ends are still colliding
+    # the same search with device tensors in and out: every round stays on the device (no host copy), bit-equal to the host loop
+    torch = torch_cuda
+    col_d = torch.from_numpy(col).cuda()
+    hi_d = counter_example_bisection(arm, seed_q, col_d, 15, 1e-6)
+    assert hi_d.is_cuda and np.array_equal(hi_d.cpu().numpy(), hi)
+    hi_g = counter_example_bisection(arm, seed_q, col_d, 15, 1e-6, graph=True)       # rounds 3..15 replayed from one hipGraph
+    assert np.array_equal(hi_g.cpu().numpy(), hi)
 
 
 def _tree_scene():
