@@ -42,6 +42,8 @@ struct DevModel {
     const double* joint_trans;    // [J][3]
     const double* joint_slide;    // [J][3]
     const double* joint_axis;     // [J][3]
+    const double* joint_pk;       // [J][22] axis-aligned joints: (M2[r][U], M2[r][V]) r = 0..2 | (M1[r][U], M1[r][V]) | M0[r][KZ] | trans | axis | pad -- what
+                                  //         joint_apply_axis reads, back to back (one prefetchable block per joint: k_jacobian_reg)
     const double* base_pose;      // [12]
     const int* rs_kind;           // [S] core kind, in frame order
     const int* rs_row;            // [S] first LDS row
@@ -158,7 +160,7 @@ struct nbk_model {
     // pairs a call can produce items for at ITS threshold and size queues / tiles for those instead of for every pair
     std::vector<double> h_static, h_m0, h_m1;
     std::vector<int> h_cat, h_cls;
-    std::vector<int> h_joint_qidx, h_joint_type;   // host copies for make_path
+    std::vector<int> h_joint_qidx, h_joint_type, h_joint_kind;   // host copies for make_path
     std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
     bool gjk_any_hull = false;         // ... and whether one of them has a hull core (those always take the distance iteration)
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
@@ -296,9 +298,44 @@ NBK_DEV void joint_apply(const DevModel& m, int k, const Xf& parent, double qk, 
     xf_mul(parent, L, tl, out);
 }
 
+// joint_apply for the kernel that unrolls a path of at most 8 joints at compile time (k_jacobian_reg): the joint's kind comes
+// from the launch arguments and its constants from ONE 144-byte block (joint_pk) that the caller loads a joint ahead, instead of a
+// kind load -> branch -> table loads -> wait chain per joint.  Same operations in the same order as joint_apply_axis: bit-identical.
+struct alignas(16) JPkD { double v[22]; };       // [18..20]: the joint axis (k_jacobian_reg), [21] pad
+template <int KZ>
+NBK_DEV void joint_apply_axis_pk(const JPkD& jp, const Xf& a, double qk, double s, double c, Xf& o) {
+    constexpr int U = (KZ + 1) % 3, V = (KZ + 2) % 3;
+    double Lu[3], Lv[3], tl[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Lu[r] = NBK_FMA(s, jp.v[2 * r], NBK_FMA(-c, jp.v[6 + 2 * r], 0.0));
+        Lv[r] = NBK_FMA(s, jp.v[2 * r + 1], NBK_FMA(-c, jp.v[6 + 2 * r + 1], 0.0));
+        tl[r] = NBK_FMA(qk, 0.0, jp.v[15 + r]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double a0 = a.R[3 * i], a1 = a.R[3 * i + 1], a2 = a.R[3 * i + 2];
+        o.R[3 * i + U] = NBK_FMA(a2, Lu[2], NBK_FMA(a1, Lu[1], a0 * Lu[0]));
+        o.R[3 * i + V] = NBK_FMA(a2, Lv[2], NBK_FMA(a1, Lv[1], a0 * Lv[0]));
+        o.R[3 * i + KZ] = NBK_FMA(a2, jp.v[14], NBK_FMA(a1, jp.v[13], a0 * jp.v[12]));
+        o.t[i] = NBK_FMA(a2, tl[2], NBK_FMA(a1, tl[1], NBK_FMA(a0, tl[0], a.t[i])));
+    }
+}
+NBK_DEV void joint_apply_pk(const DevModel& m, int k, int kind, const JPkD& jp, const Xf& parent, double qk, Xf& out) {
+    if (kind <= 2) {
+        double s = 0.0, c = 0.0;
+        nbk_sincos(qk, s, c);
+        if (kind == 0) joint_apply_axis_pk<0>(jp, parent, qk, s, c, out);
+        else if (kind == 1) joint_apply_axis_pk<1>(jp, parent, qk, s, c, out);
+        else joint_apply_axis_pk<2>(jp, parent, qk, s, c, out);
+        return;
+    }
+    joint_apply(m, k, parent, qk, out);                 // general revolute / prismatic: the table-driven form
+}
+
 // ---- FK of one frame -----------------------------------------------------------------------------
 // col / revolute / covered restate joint_qidx / joint_type along the path, so that kernels find them in scalar registers
-struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; int col[NBK_MAX_JOINTS]; unsigned revolute, covered; };
+struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; int col[NBK_MAX_JOINTS]; unsigned revolute, covered; unsigned char kind[NBK_MAX_JOINTS]; };
 
 // LDS: the raw q slab (64*n_q doubles) and the output rows (64 * 17 doubles) share one region: every q
 // value is in a register before the first pose element is written, so 8.7 KB per wave is all it takes and
@@ -511,22 +548,29 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
     double Wx[NJ][3], Ox[NJ][3];
     Xf T;
     xf_from12(m.base_pose, T);
+    // every q value of the path up front, every joint's constants one joint ahead (joint_apply_pk)
+    double qv[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) qv[i] = myq[path.col[i]];
+    JPkD jcur = *reinterpret_cast<const JPkD*>(m.joint_pk + 22 * path.idx[0]);
 #pragma unroll
     for (int i = 0; i < NJ; ++i) {
+        const JPkD jnxt = *reinterpret_cast<const JPkD*>(m.joint_pk + 22 * path.idx[i + 1 < NJ ? i + 1 : NJ - 1]);
 #pragma unroll
         for (int r = 0; r < 3; ++r) { Wx[i][r] = 0.0; Ox[i][r] = 0.0; }
         if (i < path.len) {
             const int k = path.idx[i];
             Xf nxt;
-            joint_apply(m, k, T, myq[path.col[i]], nxt);
+            joint_apply_pk(m, k, (int)path.kind[i], jcur, T, qv[i], nxt);
             T = nxt;
-            const double* a = m.joint_axis + 3 * k;
+            const double* a = jcur.v + 18;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 Wx[i][r] = NBK_FMA(T.R[3 * r + 2], a[2], NBK_FMA(T.R[3 * r + 1], a[1], T.R[3 * r] * a[0]));
                 Ox[i][r] = T.t[r];
             }
         }
+        jcur = jnxt;
     }
     Xf loc, E;
     xf_from12(path.local, loc);
@@ -3660,6 +3704,17 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     const size_t o_jk = B.add(joint_kind.data(), sizeof(int) * J);
     o.jtr = B.add(jtrans.data(), sizeof(double) * 3 * J);
     o.jsl = B.add(d->joint_slide, sizeof(double) * 3 * J);
+    std::vector<double> joint_pk(22 * (size_t)(J > 0 ? J : 1), 0.0);
+    for (int k = 0; k < J; ++k) {
+        const double* Mk = &jrot[27 * (size_t)k];
+        const int kz = joint_kind[k] <= 2 ? joint_kind[k] : 0;
+        const int u = (kz + 1) % 3, v = (kz + 2) % 3;
+        double* jp = &joint_pk[22 * (size_t)k];
+        for (int r = 0; r < 3; ++r) jp[18 + r] = d->joint_axis[3 * k + r];
+        for (int r = 0; r < 3; ++r) { jp[2 * r] = Mk[18 + 3 * r + u]; jp[2 * r + 1] = Mk[18 + 3 * r + v]; jp[6 + 2 * r] = Mk[9 + 3 * r + u]; jp[6 + 2 * r + 1] = Mk[9 + 3 * r + v]; jp[12 + r] = Mk[3 * r + kz]; jp[15 + r] = jtrans[3 * k + r]; }
+    }
+    const size_t o_jpk = B.add(joint_pk.data(), sizeof(double) * joint_pk.size());
+    M->h_joint_kind.assign(joint_kind.begin(), joint_kind.end());
     o.jax = B.add(d->joint_axis, sizeof(double) * 3 * J);
     o.bp = B.add(d->base_pose, sizeof(double) * 12);
     o.rk = B.add(rs_kind.data(), sizeof(int) * S);
@@ -3862,6 +3917,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     m.joint_trans = reinterpret_cast<const double*>(base + o.jtr);
     m.joint_slide = reinterpret_cast<const double*>(base + o.jsl);
     m.joint_axis = reinterpret_cast<const double*>(base + o.jax);
+    m.joint_pk = reinterpret_cast<const double*>(base + o_jpk);
     m.base_pose = reinterpret_cast<const double*>(base + o.bp);
     m.rs_kind = reinterpret_cast<const int*>(base + o.rk);
     m.rs_row = reinterpret_cast<const int*>(base + o.rr);
@@ -3986,6 +4042,7 @@ static int make_path(const nbk_model* m, const int32_t* path, int32_t path_len, 
         if (pa.col[i] >= 0 && pa.col[i] < 32) pa.covered |= 1u << pa.col[i];
     }
     for (int i = path_len; i < NBK_MAX_JOINTS; ++i) { pa.idx[i] = 0; pa.col[i] = 0; }
+    for (int i = 0; i < NBK_MAX_JOINTS; ++i) pa.kind[i] = (unsigned char)(i < path_len ? m->h_joint_kind[path[i]] : 0);
     memcpy(pa.local, local, sizeof(double) * 12);
     return NBK_OK;
 }
