@@ -180,7 +180,9 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
             axpy3(-wu, s.ax[2], t, w);
             const double ww = dot3(w, w);
             axpy3(sg, s.ax[2], s.c, o);
-            if (ww > 0.0) {
+            // (a direction axial to 1e-13 has no radial part worth the name: see the oracle)
+            const double u4 = (uu * uu) * (uu * uu);
+            if (ww > (1e-26 * u4) * dot3(d, d)) {
                 const double k = s.rad / nbk_sqrt(ww);
                 axpy3(k, w, o, o);
             }

@@ -421,7 +421,12 @@ static void core_support(const core_t *s, const double *d, double *o) {
             axpy3(-wu, u, t, w);
             const double ww = dot3(w, w);
             axpy3(sg, u, s->c, o);
-            if (ww > 0.0) {
+            /* a direction that is axial to 1e-13 has NO radial part worth the name: what the two passes leave is rounding noise
+             * of arbitrary direction (axial included), and scaling it to the radius puts the "support point" off the cylinder --
+             * EPA asks for exactly such directions (a face normal of A (-) B that IS the cylinder axis).  The cap centre is a
+             * support point of an axial direction; the error of its projection is below rad * 1e-13. */
+            const double u4 = (uu * uu) * (uu * uu);
+            if (ww > (1e-26 * u4) * dot3(d, d)) {
                 const double k = s->rad / sqrt(ww);
                 axpy3(k, w, o, o);
             }
@@ -671,6 +676,7 @@ static int gjk_cores(const core_t *A, const core_t *Bc, double *pa, double *pb, 
 }
 
 static double overlap_depth(const core_t *A, const core_t *Bc, double *normal);
+static double overlap_depth_exact(const core_t *A, const core_t *Bc, double *normal);
 
 /* GJK predicate: is dist(coreA, coreB) < tc ?  Same iteration as gjk_cores, but it stops as soon as the
  * support-plane lower bound reaches tc (free) or the simplex point drops below tc (colliding). */
@@ -717,7 +723,7 @@ static int gjk_collides_it(const core_t *A, const core_t *Bc, double tc, int *it
             if (sep) break;
             if (tc >= 0.0) return 1;
             double nrm[3];
-            return -overlap_depth(A, Bc, nrm) < tc;
+            return -overlap_depth_exact(A, Bc, nrm) < tc;
         }
         if (st == 2) break;
         if (tc > 0.0 && vv_prev < tc2) return 1;
@@ -951,7 +957,7 @@ static double cores_distance(const core_t *A, const core_t *Bc, double *wit, int
             const double inv = 1.0 / dc;
             n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
         } else {
-            const double depth = overlap_depth(A, Bc, n);
+            const double depth = overlap_depth_exact(A, Bc, n);
             dc = -depth;
             double neg[3] = {-n[0], -n[1], -n[2]};
             core_support(A, neg, pa);      /* deepest point of A along the normal */
@@ -1112,6 +1118,150 @@ void orc_pred_hist(long long *out, int reset) {
 }
 
 /* bounding radius of a core about its centre (broadphase) */
+/* ---- exact penetration depth of overlapping cores with a cylinder or a hull: EPA ------------------------------------------
+ * (the axis family above is exact for point / segment / box cores -- box-box = the 15 SAT axes -- but only an upper bound once
+ * a cylinder or a hull core is involved: no rim / edge-edge directions.  Bullet runs EPA on the rounded shapes here,
+ * btGjkEpaPenetrationDepthSolver; the depth of core (+) ball(m) pairs is the depth of the cores plus the margins.)
+ * M = A (-) B contains the origin.  A polytope P inside M -- first the tetrahedron of M's support points along four tetrahedral
+ * directions, faces oriented away from its centroid -- is grown: take the face with the smallest SIGNED distance d of its plane
+ * from the origin along its outward unit normal n (negative while the origin is still outside P), ask M for its support point w
+ * in direction n; n.w - d is the gap between P and M along n: converged when it is below 1e-10 (1 + n.w) with the origin inside,
+ * else w becomes a vertex (the faces that see it go, the horizon is fanned to w).  Once the origin is inside,
+ * d <= depth <= n.w; reported: depth = the smallest n.w seen, direction n.  No dependence on how GJK ended.
+ * Returns 0 (the caller keeps the axis-family value) when the start tetrahedron is flat or the polytope breaks down. */
+#define EPA_MAXV 100
+#define EPA_MAXF 224
+#define EPA_MAXIT 96
+typedef struct { double v[EPA_MAXV][3]; int nv; int f[EPA_MAXF][3]; double fd[EPA_MAXF]; int alive[EPA_MAXF]; int nf; double ref[3]; } epa_t;
+
+static int epa_face_plane(const epa_t *e, int i, int j, int k, double *n, double *d) {
+    double ab[3], ac[3], c[3];
+    sub3(e->v[j], e->v[i], ab); sub3(e->v[k], e->v[i], ac);
+    cross3(ab, ac, c);
+    const double cc = dot3(c, c);
+    if (!(cc > 1e-60)) return 0;
+    const double inv = 1.0 / sqrt(cc);
+    n[0] = c[0] * inv; n[1] = c[1] * inv; n[2] = c[2] * inv;
+    *d = dot3(n, e->v[i]);
+    return 1;
+}
+/* add face (i, j, k), oriented so that its normal points away from the reference point inside P; 0 = degenerate / no room */
+static int epa_add_face(epa_t *e, int i, int j, int k) {
+    double n[3], d, r[3];
+    if (!epa_face_plane(e, i, j, k, n, &d)) return 0;
+    sub3(e->v[i], e->ref, r);
+    if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; }
+    int slot = -1;
+    for (int q = 0; q < e->nf; ++q) if (!e->alive[q]) { slot = q; break; }
+    if (slot < 0) { if (e->nf >= EPA_MAXF) return 0; slot = e->nf++; }
+    e->f[slot][0] = i; e->f[slot][1] = j; e->f[slot][2] = k; e->fd[slot] = d; e->alive[slot] = 1;
+    return 1;
+}
+static long long g_epa_calls = 0, g_epa_fail = 0, g_epa_iters = 0;
+static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *normal) {
+    __atomic_add_fetch(&g_epa_calls, 1, __ATOMIC_RELAXED);
+    epa_t e;
+    {   /* start tetrahedron: two support points along a fixed skew direction and its opposite, the support point farthest from
+         * their line among the two along +-(a coordinate axis made perpendicular to it), the one farthest from that triangle's
+         * plane among the two along +-(its normal).  Flat only when M is (both cores small against the rounding of their positions) */
+        static const double D0[3] = {0.5345224838248488, -0.2672612419124244, 0.8017837257372732};
+        const double nD0[3] = {-D0[0], -D0[1], -D0[2]};
+        mink_support(A, Bc, D0, e.v[0]);
+        mink_support(A, Bc, nD0, e.v[1]);
+        double e1[3];
+        sub3(e.v[1], e.v[0], e1);
+        const double l1 = dot3(e1, e1);
+        if (!(l1 > 1e-30)) { __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED); return 0; }
+        const double ax = fabs(e1[0]), ay = fabs(e1[1]), az = fabs(e1[2]);
+        double a[3] = {0.0, 0.0, 0.0};
+        if (ax <= ay && ax <= az) a[0] = 1.0; else if (ay <= az) a[1] = 1.0; else a[2] = 1.0;
+        double n2[3], nn2[3], pa2[3], pb2[3], ca[3], cb[3], ra[3], rb[3];
+        axpy3(-dot3(a, e1) / l1, e1, a, n2);
+        nn2[0] = -n2[0]; nn2[1] = -n2[1]; nn2[2] = -n2[2];
+        mink_support(A, Bc, n2, pa2);
+        mink_support(A, Bc, nn2, pb2);
+        sub3(pa2, e.v[0], ra); sub3(pb2, e.v[0], rb);
+        cross3(e1, ra, ca); cross3(e1, rb, cb);
+        const int use_a = dot3(ca, ca) >= dot3(cb, cb);
+        memcpy(e.v[2], use_a ? pa2 : pb2, 24);
+        double n3[3], nn3[3], pa3[3], pb3[3];
+        memcpy(n3, use_a ? ca : cb, 24);
+        const double l3 = dot3(n3, n3);
+        if (!(l3 > 1e-24 * l1 * l1)) { __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED); return 0; }
+        nn3[0] = -n3[0]; nn3[1] = -n3[1]; nn3[2] = -n3[2];
+        mink_support(A, Bc, n3, pa3);
+        mink_support(A, Bc, nn3, pb3);
+        sub3(pa3, e.v[0], ra); sub3(pb3, e.v[0], rb);
+        const double ha = fabs(dot3(n3, ra)), hb = fabs(dot3(n3, rb));
+        memcpy(e.v[3], ha >= hb ? pa3 : pb3, 24);
+        const double hh = ha >= hb ? ha : hb;
+        if (getenv("NBK_EPA_DEBUG")) fprintf(stderr, "epa start l1 %.3g l3 %.3g hh %.3g kinds %d %d\n", l1, l3, hh, A->kind, Bc->kind);
+        if (!(hh * hh > 1e-24 * l3 * l1)) { __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED); return 0; }
+    }
+    for (int c = 0; c < 3; ++c) e.ref[c] = 0.25 * (((e.v[0][c] + e.v[1][c]) + e.v[2][c]) + e.v[3][c]);
+    e.nv = 4; e.nf = 0;
+    if (!epa_add_face(&e, 0, 1, 2) || !epa_add_face(&e, 0, 1, 3) || !epa_add_face(&e, 0, 2, 3) || !epa_add_face(&e, 1, 2, 3)) {
+        __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED); return 0;
+    }
+    double best_up = INFINITY, best_n[3] = {1.0, 0.0, 0.0};
+    int ok = 0;
+    for (int it = 0; it < EPA_MAXIT; ++it) {
+        int bf = -1;
+        for (int q = 0; q < e.nf; ++q) if (e.alive[q] && (bf < 0 || e.fd[q] < e.fd[bf])) bf = q;
+        if (bf < 0) break;
+        double n[3], d;
+        if (!epa_face_plane(&e, e.f[bf][0], e.f[bf][1], e.f[bf][2], n, &d)) break;
+        double w[3];
+        mink_support(A, Bc, n, w);
+        const double dw = dot3(n, w);
+        if (getenv("NBK_EPA_DEBUG")) fprintf(stderr, "epa it %d nf %d nv %d face %d d %.6g dw %.6g\n", it, e.nf, e.nv, bf, d, dw);
+        if (dw < best_up) { best_up = dw; best_n[0] = n[0]; best_n[1] = n[1]; best_n[2] = n[2]; }
+        __atomic_add_fetch(&g_epa_iters, 1, __ATOMIC_RELAXED);
+        if (dw - d <= 1e-10 * (1.0 + fabs(dw))) { ok = 1; break; }       /* (d < 0 here: the origin is outside M by -d: a contact within rounding) */
+        if (e.nv >= EPA_MAXV) break;
+        const int wi = e.nv++;
+        memcpy(e.v[wi], w, 24);
+        /* faces that see w go; their edges that are not shared with another such face are the horizon */
+        int edges[3 * EPA_MAXF][2], ne = 0;
+        for (int q = 0; q < e.nf; ++q) {
+            if (!e.alive[q]) continue;
+            double fn[3], fdist;
+            if (!epa_face_plane(&e, e.f[q][0], e.f[q][1], e.f[q][2], fn, &fdist)) { e.alive[q] = 0; continue; }
+            if (dot3(fn, w) - fdist <= 0.0) continue;
+            e.alive[q] = 0;
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int a = e.f[q][s3], b = e.f[q][(s3 + 1) % 3];
+                int found = -1;
+                for (int t = 0; t < ne; ++t) if ((edges[t][0] == b && edges[t][1] == a) || (edges[t][0] == a && edges[t][1] == b)) { found = t; break; }
+                if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; --ne; }
+                else { edges[ne][0] = a; edges[ne][1] = b; ++ne; }
+            }
+        }
+        if (ne < 3) break;
+        int bad = 0;
+        for (int t = 0; t < ne; ++t) if (!epa_add_face(&e, edges[t][0], edges[t][1], wi)) { bad = 1; break; }
+        if (bad) break;
+    }
+    if (!(best_up < INFINITY)) { __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED); return 0; }
+    if (!ok) __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED);
+    *depth = best_up > 0.0 ? best_up : 0.0;
+    normal[0] = -best_n[0]; normal[1] = -best_n[1]; normal[2] = -best_n[2];      /* from B to A */
+    return 1;
+}
+void orc_epa_stats(long long *out, int reset) {
+    out[0] = g_epa_calls; out[1] = g_epa_fail; out[2] = g_epa_iters;
+    if (reset) { g_epa_calls = 0; g_epa_fail = 0; g_epa_iters = 0; }
+}
+/* depth and direction (from B to A) of two overlapping cores: the axis family, tightened by EPA where the family is only a bound */
+static double overlap_depth_exact(const core_t *A, const core_t *Bc, double *normal) {
+    double depth = overlap_depth(A, Bc, normal);
+    if (A->kind == K_CYL || A->kind == K_HULL || Bc->kind == K_CYL || Bc->kind == K_HULL) {
+        double de, ne[3];
+        if (epa_depth(A, Bc, &de, ne) && de < depth) { depth = de; normal[0] = ne[0]; normal[1] = ne[1]; normal[2] = ne[2]; }
+    }
+    return depth;
+}
+
 static double core_bound_radius(const core_t *s) {
     switch (s->kind) {
         case K_POINT: return 0.0;
