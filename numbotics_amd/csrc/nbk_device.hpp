@@ -798,11 +798,146 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
     return best;
 }
 
+__device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double* out);
 __device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc) {
     double nrm[3];
-    if (A.rad > 0.0 && A.kind == K_HULL) return overlap_depth<true>(A, Bc, nrm);
-    if (Bc.rad > 0.0 && Bc.kind == K_HULL) return overlap_depth<true>(A, Bc, nrm);
-    return overlap_depth<false>(A, Bc, nrm);
+    double depth;
+    const bool lds_a = A.rad > 0.0 && A.kind == K_HULL, lds_b = Bc.rad > 0.0 && Bc.kind == K_HULL;
+    if (lds_a || lds_b) depth = overlap_depth<true>(A, Bc, nrm);
+    else depth = overlap_depth<false>(A, Bc, nrm);
+    if (A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL) {
+        // (hull cores staged in LDS keep their LDS byte address in `rad`: the support routine ignores it)
+        double o[4];
+        if (epa_depth_copy(A, Bc, o) && o[0] < depth) depth = o[0];
+    }
+    return depth;
+}
+
+// ---- exact penetration depth of overlapping cores with a cylinder or a hull: EPA (mirrors epa_depth of the oracle line by line:
+// same operations in the same order, so the same bits).  The polytope lives in per-lane arrays (scratch): only the kernels that can
+// meet overlapping cores in a distance or in a negative-threshold predicate carry it, through ONE out-of-line call.
+#define EPA_MAXIT 64
+#define EPA_MAXV (4 + EPA_MAXIT)
+#define EPA_MAXF (4 + 2 * EPA_MAXIT + 8)
+#define EPA_MAXE 64
+struct Epa { double v[EPA_MAXV][3]; int nv; short f[EPA_MAXF][3]; double fd[EPA_MAXF]; int nf; double ref[3]; };   // f[q][0] < 0: a free slot
+
+NBK_DEV bool epa_face_plane(const Epa& e, int i, int j, int k, double* n, double& d) {
+    double ab[3], ac[3], c[3];
+    sub3(e.v[j], e.v[i], ab); sub3(e.v[k], e.v[i], ac);
+    cross3(ab, ac, c);
+    const double cc = dot3(c, c);
+    if (!(cc > 1e-60)) return false;
+    const double inv = 1.0 / nbk_sqrt(cc);
+    n[0] = c[0] * inv; n[1] = c[1] * inv; n[2] = c[2] * inv;
+    d = dot3(n, e.v[i]);
+    return true;
+}
+NBK_DEV bool epa_add_face(Epa& e, int i, int j, int k) {
+    double n[3], d, r[3];
+    if (!epa_face_plane(e, i, j, k, n, d)) return false;
+    sub3(e.v[i], e.ref, r);
+    if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; }
+    int slot = -1;
+    for (int q = 0; q < e.nf; ++q) if (e.f[q][0] < 0) { slot = q; break; }
+    if (slot < 0) { if (e.nf >= EPA_MAXF) return false; slot = e.nf++; }
+    e.f[slot][0] = (short)i; e.f[slot][1] = (short)j; e.f[slot][2] = (short)k; e.fd[slot] = d;
+    return true;
+}
+// out[0] = depth, out[1..3] = direction from B to A; false: no answer (the caller keeps the axis-family value)
+__device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double* out) {
+    Epa e;
+    {
+        const double D0[3] = {0.5345224838248488, -0.2672612419124244, 0.8017837257372732};
+        const double nD0[3] = {-D0[0], -D0[1], -D0[2]};
+        mink_support(A, Bc, D0, e.v[0]);
+        mink_support(A, Bc, nD0, e.v[1]);
+        double e1[3];
+        sub3(e.v[1], e.v[0], e1);
+        const double l1 = dot3(e1, e1);
+        if (!(l1 > 1e-30)) return false;
+        const double ax = __builtin_fabs(e1[0]), ay = __builtin_fabs(e1[1]), az = __builtin_fabs(e1[2]);
+        double a[3] = {0.0, 0.0, 0.0};
+        if (ax <= ay && ax <= az) a[0] = 1.0; else if (ay <= az) a[1] = 1.0; else a[2] = 1.0;
+        double n2[3], nn2[3], pa2[3], pb2[3], ca[3], cb[3], ra[3], rb[3];
+        axpy3(-dot3(a, e1) / l1, e1, a, n2);
+        nn2[0] = -n2[0]; nn2[1] = -n2[1]; nn2[2] = -n2[2];
+        mink_support(A, Bc, n2, pa2);
+        mink_support(A, Bc, nn2, pb2);
+        sub3(pa2, e.v[0], ra); sub3(pb2, e.v[0], rb);
+        cross3(e1, ra, ca); cross3(e1, rb, cb);
+        const bool use_a = dot3(ca, ca) >= dot3(cb, cb);
+        copy3(use_a ? pa2 : pb2, e.v[2]);
+        double n3[3], nn3[3], pa3[3], pb3[3];
+        copy3(use_a ? ca : cb, n3);
+        const double l3 = dot3(n3, n3);
+        if (!(l3 > 1e-24 * l1 * l1)) return false;
+        nn3[0] = -n3[0]; nn3[1] = -n3[1]; nn3[2] = -n3[2];
+        mink_support(A, Bc, n3, pa3);
+        mink_support(A, Bc, nn3, pb3);
+        sub3(pa3, e.v[0], ra); sub3(pb3, e.v[0], rb);
+        const double ha = __builtin_fabs(dot3(n3, ra)), hb = __builtin_fabs(dot3(n3, rb));
+        copy3(ha >= hb ? pa3 : pb3, e.v[3]);
+        const double hh = ha >= hb ? ha : hb;
+        if (!(hh * hh > 1e-24 * l3 * l1)) return false;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e.ref[c] = 0.25 * (((e.v[0][c] + e.v[1][c]) + e.v[2][c]) + e.v[3][c]);
+    e.nv = 4; e.nf = 0;
+    if (!epa_add_face(e, 0, 1, 2) || !epa_add_face(e, 0, 1, 3) || !epa_add_face(e, 0, 2, 3) || !epa_add_face(e, 1, 2, 3)) return false;
+    double best_up = NBK_INF, best_n[3] = {1.0, 0.0, 0.0};
+    for (int it = 0; it < EPA_MAXIT; ++it) {
+        int bf = -1;
+        for (int q = 0; q < e.nf; ++q) if (e.f[q][0] >= 0 && (bf < 0 || e.fd[q] < e.fd[bf])) bf = q;
+        if (bf < 0) break;
+        double n[3], d;
+        if (!epa_face_plane(e, e.f[bf][0], e.f[bf][1], e.f[bf][2], n, d)) break;
+        double w[3];
+        mink_support(A, Bc, n, w);
+        const double dw = dot3(n, w);
+        if (dw < best_up) { best_up = dw; best_n[0] = n[0]; best_n[1] = n[1]; best_n[2] = n[2]; }
+        if (dw - d <= 1e-10 * (1.0 + __builtin_fabs(dw))) break;
+        if (e.nv >= EPA_MAXV) break;
+        const int wi = e.nv++;
+        copy3(w, e.v[wi]);
+        short edges[EPA_MAXE][2];
+        int ne = 0;
+        bool overflow = false;
+        for (int q = 0; q < e.nf; ++q) {
+            if (e.f[q][0] < 0) continue;
+            double fn[3], fdist;
+            if (!epa_face_plane(e, e.f[q][0], e.f[q][1], e.f[q][2], fn, fdist)) { e.f[q][0] = -1; continue; }
+            if (dot3(fn, w) - fdist <= 0.0) continue;
+            const int fv[3] = {e.f[q][0], e.f[q][1], e.f[q][2]};
+            e.f[q][0] = -1;
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const int a = fv[s3], b = fv[(s3 + 1) % 3];
+                int found = -1;
+                for (int t = 0; t < ne; ++t) if ((edges[t][0] == b && edges[t][1] == a) || (edges[t][0] == a && edges[t][1] == b)) { found = t; break; }
+                if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; --ne; }
+                else if (ne < EPA_MAXE) { edges[ne][0] = (short)a; edges[ne][1] = (short)b; ++ne; }
+                else overflow = true;
+            }
+        }
+        if (ne < 3 || overflow) break;
+        bool bad = false;
+        for (int t = 0; t < ne; ++t) if (!epa_add_face(e, edges[t][0], edges[t][1], wi)) { bad = true; break; }
+        if (bad) break;
+    }
+    if (!(best_up < NBK_INF)) return false;
+    out[0] = best_up > 0.0 ? best_up : 0.0;
+    out[1] = -best_n[0]; out[2] = -best_n[1]; out[3] = -best_n[2];
+    return true;
+}
+// depth and direction (from B to A) of two overlapping cores: the axis family, tightened by EPA where the family is only a bound
+template <bool LDSV = false>
+NBK_DEV double overlap_depth_exact(const Core& A, const Core& Bc, double* normal) {
+    double depth = overlap_depth<LDSV>(A, Bc, normal);
+    if (A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL) {
+        double o[4];
+        if (epa_depth_copy(A, Bc, o) && o[0] < depth) { depth = o[0]; normal[0] = o[1]; normal[1] = o[2]; normal[2] = o[3]; }
+    }
+    return depth;
 }
 
 // ---- closed forms for point / segment cores ---------------------------------------------------
@@ -967,7 +1102,7 @@ NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
                 n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
             }
         } else {
-            const double depth = overlap_depth(A, Bc, n);
+            const double depth = overlap_depth_exact(A, Bc, n);
             dc = -depth;
             if constexpr (WIT) {
                 const double neg[3] = {-n[0], -n[1], -n[2]};

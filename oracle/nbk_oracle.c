@@ -1129,9 +1129,10 @@ void orc_pred_hist(long long *out, int reset) {
  * else w becomes a vertex (the faces that see it go, the horizon is fanned to w).  Once the origin is inside,
  * d <= depth <= n.w; reported: depth = the smallest n.w seen, direction n.  No dependence on how GJK ended.
  * Returns 0 (the caller keeps the axis-family value) when the start tetrahedron is flat or the polytope breaks down. */
-#define EPA_MAXV 100
-#define EPA_MAXF 224
-#define EPA_MAXIT 96
+#define EPA_MAXIT 64
+#define EPA_MAXV (4 + EPA_MAXIT)
+#define EPA_MAXF (4 + 2 * EPA_MAXIT + 8)
+#define EPA_MAXE 64
 typedef struct { double v[EPA_MAXV][3]; int nv; int f[EPA_MAXF][3]; double fd[EPA_MAXF]; int alive[EPA_MAXF]; int nf; double ref[3]; } epa_t;
 
 static int epa_face_plane(const epa_t *e, int i, int j, int k, double *n, double *d) {
@@ -1222,7 +1223,7 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
         const int wi = e.nv++;
         memcpy(e.v[wi], w, 24);
         /* faces that see w go; their edges that are not shared with another such face are the horizon */
-        int edges[3 * EPA_MAXF][2], ne = 0;
+        int edges[EPA_MAXE][2], ne = 0, overflow = 0;
         for (int q = 0; q < e.nf; ++q) {
             if (!e.alive[q]) continue;
             double fn[3], fdist;
@@ -1234,10 +1235,11 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
                 int found = -1;
                 for (int t = 0; t < ne; ++t) if ((edges[t][0] == b && edges[t][1] == a) || (edges[t][0] == a && edges[t][1] == b)) { found = t; break; }
                 if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; --ne; }
-                else { edges[ne][0] = a; edges[ne][1] = b; ++ne; }
+                else if (ne < EPA_MAXE) { edges[ne][0] = a; edges[ne][1] = b; ++ne; }
+                else overflow = 1;
             }
         }
-        if (ne < 3) break;
+        if (ne < 3 || overflow) break;
         int bad = 0;
         for (int t = 0; t < ne; ++t) if (!epa_add_face(&e, edges[t][0], edges[t][1], wi)) { bad = 1; break; }
         if (bad) break;
