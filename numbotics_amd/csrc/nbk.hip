@@ -2937,6 +2937,33 @@ __global__ __launch_bounds__(NARROW_T, 2) void k_narrow_pos(DevModel m, EdgeSrc 
 // MODE 3: distances + witnesses + proximity-Jacobian rows (Arm.jacobian_proximity, arm.py:620-632):
 //         row[col(k)] = n . Jv_subject,k(p_s) - n . Jv_target,k(p_t) over the joints k above each shape, with
 //         Jv_k(r) = w_k x (r - o_k) (revolute) or w_k (prismatic); world targets contribute nothing.
+// one row of the proximity Jacobian (MODE 3) of pair p for the configuration parked in LDS column `col`
+NBK_DEV void prox_row(const DevModel& m, const double* lds_jz, int col, int p, const double* wit, double* row) {
+    for (int c = 0; c < m.n_q; ++c) row[c] = 0.0;
+    const int sa = m.pair_a[p], sb = m.pair_b[p];
+    const unsigned ma = m.rs_mask[sa];
+    const unsigned mb = sb < m.n_rshapes ? m.rs_mask[sb] : 0u;
+    for (int k = 0; k < m.n_joints; ++k) {
+        const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
+        if (!in_a && !in_b) continue;
+        const double w[3] = {lds_jz[(6 * k) * WAVE + col], lds_jz[(6 * k + 1) * WAVE + col], lds_jz[(6 * k + 2) * WAVE + col]};
+        const double o3[3] = {lds_jz[(6 * k + 3) * WAVE + col], lds_jz[(6 * k + 4) * WAVE + col], lds_jz[(6 * k + 5) * WAVE + col]};
+        const bool rev = m.joint_type[k] == NBK_REVOLUTE;
+        double va = 0.0, vb = 0.0;
+        if (in_a) {
+            if (rev) { double dd[3], v[3]; sub3(wit, o3, dd); cross3(w, dd, v); va = dot3(wit + 6, v); }
+            else va = dot3(wit + 6, w);
+        }
+        if (in_b) {
+            if (rev) { double dd[3], v[3]; sub3(wit + 3, o3, dd); cross3(w, dd, v); vb = dot3(wit + 6, v); }
+            else vb = dot3(wit + 6, w);
+        }
+        row[m.joint_qidx[k]] = va - vb;
+    }
+}
+
+constexpr int EPAQ_CAP = 128;                  // (lane, pair) items waiting for their EPA pass, per wave
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __restrict__ q, int64_t B,
                                                    double* __restrict__ out_d, int32_t* __restrict__ out_i,
@@ -2954,6 +2981,53 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     sweep_and_park(m, lds_q, lds_s, lds_fr, lane, lds_jz);
     double best = NBK_INF;
     int bi = -1;
+    // MODE >= 1: overlapping cores whose exact depth needs EPA (a cylinder or a hull) get the axis-family value first and are queued
+    // (lane, pair, family depth) in the LDS tail the validity path uses for its own queue; the queue is drained one item per lane --
+    // 64 polytopes grow side by side instead of one lane's while 63 wait -- and a better (smaller) depth overwrites the record.
+    double* epaq_depth = lds_fr + WAVE * 12 * m.frame_slots + (MODE == 3 ? WAVE * 6 * m.n_joints : 0);
+    unsigned* epaq_item = reinterpret_cast<unsigned*>(epaq_depth + EPAQ_CAP);
+    int epaq_n = 0;
+    auto epaq_drain = [&]() {
+#ifdef NBK_NO_EPA_DRAIN
+        epaq_n = 0; return;
+#endif
+        wave_lds_sync();
+        for (int i0 = 0; i0 < epaq_n; i0 += WAVE) {
+            const int i = i0 + lane;
+            if (i < epaq_n) {
+                const unsigned item = epaq_item[i];
+                const int src = (int)(item & 63u), p = (int)(item >> 6);
+                const double fam = epaq_depth[i];
+                Core A, Bc;
+                const int a = m.pair_a[p], bb = m.pair_b[p];
+                load_core_any(m, lds_s, a, src, A);
+                load_core_any(m, lds_s, bb < m.n_rshapes ? bb : ~(bb - m.n_rshapes), src, Bc);
+                double o[4];
+                if (epa_depth_copy(A, Bc, o) && o[0] < fam) {
+                    // the record of cores_distance's overlap branch, with EPA's depth and direction
+                    const double n[3] = {o[1], o[2], o[3]};
+                    const double dc = -o[0];
+                    const int64_t bs = base + src;
+                    const int64_t oo = bs * m.n_pairs + m.pair_user[p];
+                    out_d[oo] = (dc - A.margin) - Bc.margin;
+                    if constexpr (MODE >= 2) {
+                        const double neg[3] = {-n[0], -n[1], -n[2]};
+                        double pa[3], pb[3], wit[9];
+                        core_support(A, neg, pa);
+                        axpy3(dc, n, pa, pb);
+                        axpy3(-A.margin, n, pa, wit);
+                        axpy3(Bc.margin, n, pb, wit + 3);
+                        copy3(n, wit + 6);
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) out_w[oo * 9 + e] = wit[e];
+                        if constexpr (MODE == 3) prox_row(m, lds_jz, src, p, wit, out_j + oo * m.n_q);
+                    }
+                }
+            }
+        }
+        epaq_n = 0;
+        wave_lds_sync();
+    };
     // MODE >= 1: gridDim.y workgroups share the pairs of a block of configurations (each sweeps the tree itself and takes every
     // gridDim.y-th ... contiguous slice of the pair list): small batches such as IRIS' 10 071 samples would otherwise put one
     // wave per 64 samples on a 1 024-SIMD chip and walk 44 GJK distances one after the other
@@ -2963,7 +3037,8 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
         Core A, Bc;
         load_pair(m, lds_s, p, lane, A, Bc);
         double wit[9];
-        const double d = cores_distance<(MODE >= 2)>(A, Bc, wit);
+        double fam = -1.0;
+        const double d = cores_distance<(MODE >= 2), (MODE >= 1)>(A, Bc, wit, &fam);
         if constexpr (MODE == 0) {
             // pairs are visited in device order; ties resolve to the smallest USER index like the oracle
             const int u = m.pair_user[p];
@@ -2976,35 +3051,31 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
 #pragma unroll
                     for (int e = 0; e < 9; ++e) out_w[o * 9 + e] = wit[e];
                 }
-                if constexpr (MODE == 3) {
-                    double* row = out_j + o * m.n_q;
-                    for (int c = 0; c < m.n_q; ++c) row[c] = 0.0;
-                    const int sa = m.pair_a[p], sb = m.pair_b[p];
-                    const unsigned ma = m.rs_mask[sa];
-                    const unsigned mb = sb < m.n_rshapes ? m.rs_mask[sb] : 0u;
-                    for (int k = 0; k < m.n_joints; ++k) {
-                        const bool in_a = (ma >> k) & 1u, in_b = (mb >> k) & 1u;
-                        if (!in_a && !in_b) continue;
-                        const double w[3] = {lds_jz[(6 * k) * WAVE + lane], lds_jz[(6 * k + 1) * WAVE + lane], lds_jz[(6 * k + 2) * WAVE + lane]};
-                        const double o3[3] = {lds_jz[(6 * k + 3) * WAVE + lane], lds_jz[(6 * k + 4) * WAVE + lane], lds_jz[(6 * k + 5) * WAVE + lane]};
-                        const bool rev = m.joint_type[k] == NBK_REVOLUTE;
-                        double va = 0.0, vb = 0.0;
-                        if (in_a) {
-                            if (rev) { double dd[3], v[3]; sub3(wit, o3, dd); cross3(w, dd, v); va = dot3(wit + 6, v); }
-                            else va = dot3(wit + 6, w);
-                        }
-                        if (in_b) {
-                            if (rev) { double dd[3], v[3]; sub3(wit + 3, o3, dd); cross3(w, dd, v); vb = dot3(wit + 6, v); }
-                            else vb = dot3(wit + 6, w);
-                        }
-                        row[m.joint_qidx[k]] = va - vb;
-                    }
+                if constexpr (MODE == 3) prox_row(m, lds_jz, lane, p, wit, out_j + o * m.n_q);
+            }
+            const bool need = active && fam >= 0.0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+            if (bal != 0ull) {
+                if (need) {
+                    const int pos = epaq_n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                    epaq_item[pos] = ((unsigned)p << 6) | (unsigned)lane;
+                    epaq_depth[pos] = fam;
+                }
+                epaq_n += __builtin_popcountll(bal);
+                if (epaq_n > EPAQ_CAP - WAVE) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the provisional records are out before a drain overwrites them
+                    epaq_drain();
                 }
             }
         }
     }
     if constexpr (MODE == 0) {
         if (active) { out_d[b] = best; if (out_i != nullptr) out_i[b] = bi; }
+    } else {
+        if (epaq_n > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            epaq_drain();
+        }
     }
 }
 

@@ -816,11 +816,12 @@ __device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc) 
 // ---- exact penetration depth of overlapping cores with a cylinder or a hull: EPA (mirrors epa_depth of the oracle line by line:
 // same operations in the same order, so the same bits).  The polytope lives in per-lane arrays (scratch): only the kernels that can
 // meet overlapping cores in a distance or in a negative-threshold predicate carry it, through ONE out-of-line call.
-#define EPA_MAXIT 64
+#define EPA_MAXIT 32
+#define EPA_TOL 1e-8     /* relative gap between the inner polytope and the body along the nearest face's normal (Bullet's own EPA stops at 1e-4) */
 #define EPA_MAXV (4 + EPA_MAXIT)
 #define EPA_MAXF (4 + 2 * EPA_MAXIT + 8)
 #define EPA_MAXE 64
-struct Epa { double v[EPA_MAXV][3]; int nv; short f[EPA_MAXF][3]; double fd[EPA_MAXF]; int nf; double ref[3]; };   // f[q][0] < 0: a free slot
+struct Epa { double v[EPA_MAXV][3]; int nv; short f[EPA_MAXF][3]; double fn[EPA_MAXF][3]; double fd[EPA_MAXF]; int nf; double ref[3]; };   // f[q][0] < 0: a free slot
 
 NBK_DEV bool epa_face_plane(const Epa& e, int i, int j, int k, double* n, double& d) {
     double ab[3], ac[3], c[3];
@@ -837,11 +838,12 @@ NBK_DEV bool epa_add_face(Epa& e, int i, int j, int k) {
     double n[3], d, r[3];
     if (!epa_face_plane(e, i, j, k, n, d)) return false;
     sub3(e.v[i], e.ref, r);
-    if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; }
+    if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
     int slot = -1;
     for (int q = 0; q < e.nf; ++q) if (e.f[q][0] < 0) { slot = q; break; }
     if (slot < 0) { if (e.nf >= EPA_MAXF) return false; slot = e.nf++; }
     e.f[slot][0] = (short)i; e.f[slot][1] = (short)j; e.f[slot][2] = (short)k; e.fd[slot] = d;
+    e.fn[slot][0] = n[0]; e.fn[slot][1] = n[1]; e.fn[slot][2] = n[2];
     return true;
 }
 // out[0] = depth, out[1..3] = direction from B to A; false: no answer (the caller keeps the axis-family value)
@@ -890,13 +892,13 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
         int bf = -1;
         for (int q = 0; q < e.nf; ++q) if (e.f[q][0] >= 0 && (bf < 0 || e.fd[q] < e.fd[bf])) bf = q;
         if (bf < 0) break;
-        double n[3], d;
-        if (!epa_face_plane(e, e.f[bf][0], e.f[bf][1], e.f[bf][2], n, d)) break;
+        const double n[3] = {e.fn[bf][0], e.fn[bf][1], e.fn[bf][2]};
+        const double d = e.fd[bf];
         double w[3];
         mink_support(A, Bc, n, w);
         const double dw = dot3(n, w);
         if (dw < best_up) { best_up = dw; best_n[0] = n[0]; best_n[1] = n[1]; best_n[2] = n[2]; }
-        if (dw - d <= 1e-10 * (1.0 + __builtin_fabs(dw))) break;
+        if (dw - d <= EPA_TOL * (1.0 + __builtin_fabs(dw))) break;
         if (e.nv >= EPA_MAXV) break;
         const int wi = e.nv++;
         copy3(w, e.v[wi]);
@@ -905,9 +907,7 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
         bool overflow = false;
         for (int q = 0; q < e.nf; ++q) {
             if (e.f[q][0] < 0) continue;
-            double fn[3], fdist;
-            if (!epa_face_plane(e, e.f[q][0], e.f[q][1], e.f[q][2], fn, fdist)) { e.f[q][0] = -1; continue; }
-            if (dot3(fn, w) - fdist <= 0.0) continue;
+            if (dot3(e.fn[q], w) - e.fd[q] <= 0.0) continue;
             const int fv[3] = {e.f[q][0], e.f[q][1], e.f[q][2]};
             e.f[q][0] = -1;
             for (int s3 = 0; s3 < 3; ++s3) {
@@ -1045,8 +1045,11 @@ NBK_DEV double point_solid(const double* p, const Core& S, double* cp, double* n
 }
 
 // signed distance between two shapes; wit (WIT only) = point on A, point on B, unit normal B -> A
-template <bool WIT>
-NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
+// DEFER: where the exact depth of overlapping cores needs EPA (a cylinder or a hull core), return the axis-family value and its
+// depth in *defer_depth (else left untouched): the caller runs EPA for such items later, one per lane on full waves -- inline,
+// one lane would walk its polytope while 63 wait (k_distances)
+template <bool WIT, bool DEFER = false>
+NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit, double* defer_depth = nullptr) {
     double pa[3] = {0, 0, 0}, pb[3] = {0, 0, 0}, n[3] = {1, 0, 0};
     double dc;
     if (Bc.kind == K_PLANE) {
@@ -1102,7 +1105,13 @@ NBK_DEV double cores_distance(const Core& A, const Core& Bc, double* wit) {
                 n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
             }
         } else {
-            const double depth = overlap_depth_exact(A, Bc, n);
+            double depth;
+            if constexpr (DEFER) {
+                depth = overlap_depth(A, Bc, n);
+                if (A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL) *defer_depth = depth;
+            } else {
+                depth = overlap_depth_exact(A, Bc, n);
+            }
             dc = -depth;
             if constexpr (WIT) {
                 const double neg[3] = {-n[0], -n[1], -n[2]};

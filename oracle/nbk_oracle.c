@@ -1129,11 +1129,12 @@ void orc_pred_hist(long long *out, int reset) {
  * else w becomes a vertex (the faces that see it go, the horizon is fanned to w).  Once the origin is inside,
  * d <= depth <= n.w; reported: depth = the smallest n.w seen, direction n.  No dependence on how GJK ended.
  * Returns 0 (the caller keeps the axis-family value) when the start tetrahedron is flat or the polytope breaks down. */
-#define EPA_MAXIT 64
+#define EPA_MAXIT 32
+#define EPA_TOL 1e-8     /* relative gap between the inner polytope and the body along the nearest face's normal (Bullet's own EPA stops at 1e-4) */
 #define EPA_MAXV (4 + EPA_MAXIT)
 #define EPA_MAXF (4 + 2 * EPA_MAXIT + 8)
 #define EPA_MAXE 64
-typedef struct { double v[EPA_MAXV][3]; int nv; int f[EPA_MAXF][3]; double fd[EPA_MAXF]; int alive[EPA_MAXF]; int nf; double ref[3]; } epa_t;
+typedef struct { double v[EPA_MAXV][3]; int nv; int f[EPA_MAXF][3]; double fn[EPA_MAXF][3]; double fd[EPA_MAXF]; int alive[EPA_MAXF]; int nf; double ref[3]; } epa_t;
 
 static int epa_face_plane(const epa_t *e, int i, int j, int k, double *n, double *d) {
     double ab[3], ac[3], c[3];
@@ -1151,11 +1152,12 @@ static int epa_add_face(epa_t *e, int i, int j, int k) {
     double n[3], d, r[3];
     if (!epa_face_plane(e, i, j, k, n, &d)) return 0;
     sub3(e->v[i], e->ref, r);
-    if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; }
+    if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
     int slot = -1;
     for (int q = 0; q < e->nf; ++q) if (!e->alive[q]) { slot = q; break; }
     if (slot < 0) { if (e->nf >= EPA_MAXF) return 0; slot = e->nf++; }
     e->f[slot][0] = i; e->f[slot][1] = j; e->f[slot][2] = k; e->fd[slot] = d; e->alive[slot] = 1;
+    e->fn[slot][0] = n[0]; e->fn[slot][1] = n[1]; e->fn[slot][2] = n[2];       /* (kept: the plane is not derived again) */
     return 1;
 }
 static long long g_epa_calls = 0, g_epa_fail = 0, g_epa_iters = 0;
@@ -1210,15 +1212,15 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
         int bf = -1;
         for (int q = 0; q < e.nf; ++q) if (e.alive[q] && (bf < 0 || e.fd[q] < e.fd[bf])) bf = q;
         if (bf < 0) break;
-        double n[3], d;
-        if (!epa_face_plane(&e, e.f[bf][0], e.f[bf][1], e.f[bf][2], n, &d)) break;
+        const double n[3] = {e.fn[bf][0], e.fn[bf][1], e.fn[bf][2]};
+        const double d = e.fd[bf];
         double w[3];
         mink_support(A, Bc, n, w);
         const double dw = dot3(n, w);
         if (getenv("NBK_EPA_DEBUG")) fprintf(stderr, "epa it %d nf %d nv %d face %d d %.6g dw %.6g\n", it, e.nf, e.nv, bf, d, dw);
         if (dw < best_up) { best_up = dw; best_n[0] = n[0]; best_n[1] = n[1]; best_n[2] = n[2]; }
         __atomic_add_fetch(&g_epa_iters, 1, __ATOMIC_RELAXED);
-        if (dw - d <= 1e-10 * (1.0 + fabs(dw))) { ok = 1; break; }       /* (d < 0 here: the origin is outside M by -d: a contact within rounding) */
+        if (dw - d <= EPA_TOL * (1.0 + fabs(dw))) { ok = 1; break; }       /* (d < 0 here: the origin is outside M by -d: a contact within rounding) */
         if (e.nv >= EPA_MAXV) break;
         const int wi = e.nv++;
         memcpy(e.v[wi], w, 24);
@@ -1226,9 +1228,7 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
         int edges[EPA_MAXE][2], ne = 0, overflow = 0;
         for (int q = 0; q < e.nf; ++q) {
             if (!e.alive[q]) continue;
-            double fn[3], fdist;
-            if (!epa_face_plane(&e, e.f[q][0], e.f[q][1], e.f[q][2], fn, &fdist)) { e.alive[q] = 0; continue; }
-            if (dot3(fn, w) - fdist <= 0.0) continue;
+            if (dot3(e.fn[q], w) - e.fd[q] <= 0.0) continue;
             e.alive[q] = 0;
             for (int s3 = 0; s3 < 3; ++s3) {
                 const int a = e.f[q][s3], b = e.f[q][(s3 + 1) % 3];

@@ -47,9 +47,12 @@ def test_symmetry_and_predicate_consistency():
         pa, pb = random_param(rng, ta), random_param(rng, tb)
         d, wa, wb, n, it = shape_distance(ta, Ta, pa, tb, Tb, pb)
         d2, wa2, wb2, n2, _ = shape_distance(tb, Tb, pb, ta, Ta, pa)
-        assert abs(d - d2) < 1e-9 * max(1.0, abs(d))
+        # (penetration depths with a cylinder core come from EPA, which stops at a relative gap of 1e-8 or 32 vertices: the two
+        # orders, and the predicate's canonical order, agree to that -- 1e-6 is the bar the truth tests hold it to)
+        overlap_tol = 1e-6 if (d < 0 and 3 in (ta, tb)) else 1e-9 * max(1.0, abs(d))
+        assert abs(d - d2) < overlap_tol
         assert it <= 64
-        for thr in (0.0, 0.05, -0.01, d * (1 + 1e-6), d * (1 - 1e-6)):
+        for thr in (0.0, 0.05, -0.01, d + max(1e-6 * abs(d), 2 * overlap_tol), d - max(1e-6 * abs(d), 2 * overlap_tol)):
             assert shape_collides(ta, Ta, pa, tb, Tb, pb, thr) == (d < thr)
 
 

@@ -1,0 +1,20 @@
+import os, sys, torch, numpy as np
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
+from numbotics_amd import _lib
+if len(sys.argv) > 1: _lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from numbotics_amd.physics import World
+from numbotics_amd.scenes import build_scene, sample_q
+World()
+arm, chain, obs = build_scene('c2')
+sm, dev = arm._scene_device()
+q5 = torch.from_numpy(sample_q(chain, 10071, seed=31)).cuda()
+def t(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0,e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1)/n
+print(os.path.basename(_lib.LIB_PATH), 'records ms %.3f  distances ms %.3f' % (t(lambda: dev.proximity_jacobian(q5)), t(lambda: dev.pair_distances(q5))))
+d = dev.pair_distances(q5).cpu().numpy()
+print('overlapping (d<0) pair fraction', (d < 0).mean(), 'configs with any', (d < 0).any(axis=1).mean())
