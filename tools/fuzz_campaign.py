@@ -2,7 +2,7 @@
 several thresholds, device masks (two-kernel path with the float32 broadphase) against the CPU oracle.
     python tools/fuzz_campaign.py [first_seed] [n_seeds] [configs_per_seed]
 Every third seed builds its robot and obstacles WITH MESHES (random polytope files, scaled / offset / auto-centred / compound),
-every fourth compiles the scene with bullet_margins=True; NBK_FUZZ_ALL=1 adds every other entry point,
+every second compiles the scene with bullet_margins=True (the default), the others with sharp shapes; NBK_FUZZ_ALL=1 adds every other entry point,
 NBK_FUZZ_THRESHOLDS="0.05,0.2,-0.01,1e-3" replaces the four default thresholds."""
 import os, sys, tempfile, numpy as np
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
@@ -28,7 +28,7 @@ with tempfile.TemporaryDirectory() as d:
         chain = GraphChain.from_urdf(random_urdf(rng, n_links, os.path.join(d, "f.urdf"), meshes=meshes))
         if chain.dof == 0:
             continue
-        arm = Arm(chain, bullet_margins=(seed % 4 == 0))
+        arm = Arm(chain, bullet_margins=(seed % 2 == 0))
         obs = random_obstacles(rng, int(rng.integers(1, 9)), mesh_dir=d if meshes else None)
         sm = arm.scene_model()
         if sm.n_pairs == 0:
@@ -37,7 +37,7 @@ with tempfile.TemporaryDirectory() as d:
         lim = np.asarray(chain.joint_limits, dtype=np.float64)
         lim = np.where(np.isfinite(lim), lim, np.sign(lim) * np.pi)
         q = rng.uniform(lim[:, 0], lim[:, 1], (B, chain.dof))
-        line = f"seed {seed}: links {n_links} dof {chain.dof} shapes {sm.n_rshapes}+{sm.n_wshapes} pairs {sm.n_pairs} hulls {sm.n_hulls}" + (" bullet-margins" if seed % 4 == 0 else "")
+        line = f"seed {seed}: links {n_links} dof {chain.dof} shapes {sm.n_rshapes}+{sm.n_wshapes} pairs {sm.n_pairs} hulls {sm.n_hulls}" + (" bullet-margins" if seed % 2 == 0 else " sharp")
         for thr in THRESHOLDS:
             ref = orc.validity(q, thr, nthreads=16)
             got = np.asarray(arm.in_collision(q, thr))

@@ -18,7 +18,7 @@ with tempfile.TemporaryDirectory() as d:
     n_links = int(rng.integers(3, 17))
     meshes = seed % 3 == 0
     chain = GraphChain.from_urdf(random_urdf(rng, n_links, os.path.join(d, "f.urdf"), meshes=meshes))
-    arm = Arm(chain, bullet_margins=(seed % 4 == 0))
+    arm = Arm(chain, bullet_margins=(seed % 2 == 0))
     obs = random_obstacles(rng, int(rng.integers(1, 9)), mesh_dir=d if meshes else None)
     sm = arm.scene_model()
     orc = Oracle(sm)
