@@ -1918,22 +1918,15 @@ __global__ __launch_bounds__(64, 3) void k_broad_reg(DevModel m, EdgeSrc es, con
 // Tables in LDS as in k_broad_reg (keys in float32, already including the static part of the slack).
 struct XfF { float R[9]; float t[3]; };
 
-// sin / cos to ~1e-7 absolute for |x| up to a few thousand radians (two-term Cody-Waite by pi/2, Taylor on [-pi/4, pi/4]);
-// the angle error of a float32 q (6e-8 |q|) is charged to the slack by the caller
+// sin / cos for the conservative float32 sweep: the hardware's v_sin_f32 / v_cos_f32 on the fractional part of x / 2 pi (five
+// instructions where the Cody-Waite + Taylor form took 22).  Measured on the device over |x| <= 64 (tools: profiles/r03_hw_sincos.log):
+// absolute error <= 2.7e-7 for |x| <= 3.2 and <= 2.7e-7 + 4e-8 |x| beyond (the rounding of x / 2 pi) -- inside what the slack
+// charges per joint (16 ulp = 9.5e-7 for the sweep, 2.4e-7 |q| for the angle, both times 50)
 NBK_DEV void sincos_f(float x, float& s, float& c) {
-    const float k = __builtin_rintf(x * 0.63661977f);
-    float r = __builtin_fmaf(-k, 1.57079625f, x);
-    r = __builtin_fmaf(-k, 7.54978942e-8f, r);
-    const float r2 = r * r;
-    const float sp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.75573192e-6f, -1.98412698e-4f), 8.33333333e-3f), -1.66666667e-1f);
-    const float cp = __builtin_fmaf(r2, __builtin_fmaf(r2, __builtin_fmaf(r2, 2.48015873e-5f, -1.38888889e-3f), 4.16666667e-2f), -0.5f);
-    const float sr = __builtin_fmaf(r * r2, sp, r);
-    const float cr = __builtin_fmaf(r2, cp, 1.0f);
-    const int n = (int)k & 3;
-    const float s0 = (n & 1) ? cr : sr;
-    const float c0 = (n & 1) ? sr : cr;
-    s = (n & 2) ? -s0 : s0;
-    c = ((n + 1) & 2) ? -c0 : c0;
+    const float r = x * 0.15915494309189535f;
+    const float f = r - __builtin_rintf(r);
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
 }
 
 template <int KZ>

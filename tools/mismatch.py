@@ -1,6 +1,6 @@
-"""debug: where does the device mask differ from the oracle?  python tools/dbg/mismatch.py <scene> <thr> [sharp]"""
+"""debug: where does the device mask differ from the oracle?  python tools/mismatch.py <scene> <thr> [sharp]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from numbotics_amd.physics import World
 from numbotics_amd.scenes import build_scene, sample_q
