@@ -1430,6 +1430,16 @@ __global__ __launch_bounds__(256) void k_prepare_f32(DevModel m, double thr, uns
             wkey2[w * 16 + a] = cat == 0 ? ((key + rho[a]) + m.f_e2max * up) + __builtin_fabsf(key + rho[a]) * 2.4e-7f
                                          : (key >= 0.0f ? cand2(key) : -1.0f);
             wp[w * 16 + a] = p;
+            if (cat != 0 && m.ws_kind[w] == K_HULL) {
+                // the fast stage's hull slot: bounding spheres, the cull against the hull's local box, the inscribed balls
+                float* wb = wbx + w * 96 + (a / 2) * 12 + (a % 2);
+                const double tc = (thr + cst[0]) + cst[1];
+                const float tcp = tc > 0.0 ? (float)tc * up : 0.0f;
+                const float rr = ((tcp + rho[a]) + m.f_e2max * up) * up;
+                wb[0] = wkey2[w * 16 + a];
+                wb[2] = (rr * rr) * (up * up);
+                wb[4] = wcert[w * 16 + a];
+            }
             if (cat != 0 && m.ws_kind[w] == K_BOX) {
                 // the fast stage's box slot (every threshold with the STATIC slack bound, so that it is a scalar): see k_broad_f32
                 float* wb = wbx + w * 96 + (a / 2) * 12 + (a % 2);
@@ -2352,29 +2362,41 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
                 }
                 continue;
             } else if (wk == K_HULL) {
-                const float* ob = m.f_tab + m.f_wobb + 6 * w;            // the hull's local bounding box
+                // the box slot's form with the hull's local bounding box: candidate = bounding spheres (dd < wkey2) and the centre closer
+                // to that box than tc+ + rho + slack (a cull only: the box contains the hull); certain hit = the inscribed balls (dd < cert)
+                const float* ob = m.f_tab + m.f_wobb + 6 * w;
+                const float* wb = ft.wbx + w * 96;
+                int cwv[S];
+                int acc_c = 0, acc_h = 0;
 #pragma unroll
-                for (int a = 0; a < S; ++a) {
-                    if (a < m.n_rshapes && wkeyr.v[a] >= 0.0f) {
-                        const float dx = cx(a) - wc[0], dy = cy(a) - wc[1], dz = cz(a) - wc[2];
-                        const float dd = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-                        bool cand = dd < wkey2r.v[a];
-                        ch = ch || (dd < wcertr.v[a]);
-                        if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {     // centre against the hull's box: only a cull
-                            const float tc = tab_wtc[w * 16 + a], rho = tab_rho[a];
-                            float ex2 = 0.0f;
+                for (int i = 0; i < S / 2; ++i) {
+                    const V2f dx = cx2v(i) - splat2(wc[0]), dy = cy2v(i) - splat2(wc[1]), dz = cz2v(i) - splat2(wc[2]);
+                    const V2f dd = fma2(dz, dz, fma2(dy, dy, dx * dx));
+                    V2f ex2 = V2f{0.0f, 0.0f};
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const float xj = __builtin_fmaf(dz, wc[5 + 3 * j], __builtin_fmaf(dy, wc[4 + 3 * j], dx * wc[3 + 3 * j])) - ob[j];
-                                const float exj = __builtin_fabsf(xj) - ob[3 + j];
-                                if (exj > 0.0f) ex2 = __builtin_fmaf(exj, exj, ex2);
-                            }
-                            const float rr = ((tc > 0.0f ? tc : 0.0f) + rho) + e2;       // tc < 0: disjoint is enough (device-only cull)
-                            if (ex2 >= rr * rr * up) cand = false;
-                        }
-                        c[a] = cand;
+                    for (int j = 0; j < 3; ++j) {
+                        const V2f pj = fma2(dz, splat2(wc[5 + 3 * j]), fma2(dy, splat2(wc[4 + 3 * j]), dx * splat2(wc[3 + 3 * j]))) - splat2(ob[j]);
+                        const V2f cl = V2f{__builtin_fmaxf(__builtin_fabsf(pj.x) - ob[3 + j], 0.0f), __builtin_fmaxf(__builtin_fabsf(pj.y) - ob[3 + j], 0.0f)};
+                        ex2 = fma2(cl, cl, ex2);
                     }
+                    const float* tb = wb + 12 * i;
+                    const V2i s1 = __builtin_bit_cast(V2i, dd - V2f{tb[0], tb[1]});
+                    const V2i s2 = __builtin_bit_cast(V2i, ex2 - V2f{tb[2], tb[3]});
+                    const V2i s3 = __builtin_bit_cast(V2i, dd - V2f{tb[4], tb[5]});
+                    const V2i cand = s1 & s2;
+                    cwv[2 * i] = cand.x; cwv[2 * i + 1] = cand.y;
+                    acc_c |= cand.x | cand.y;
+                    acc_h |= s3.x | s3.y;
                 }
+                hit = hit || (acc_h < 0);
+                const bool live = active && !hit && !(NBK_DBG(m) & 4);
+                if (__builtin_amdgcn_ballot_w64(acc_c < 0 && live) != 0ull) {
+                    NBK_ROOM(S)
+#pragma unroll
+                    for (int a = 0; a < S; ++a)
+                        if (a < m.n_rshapes) NBK_ENQUEUE(cwv[a] < 0 && live, tab_wp[w * 16 + a]);
+                }
+                continue;
             } else {
 #pragma unroll
                 for (int a = 0; a < S; ++a) {

@@ -4,7 +4,7 @@
 # than --kernel-trace), outputs under gpurun_out/<tag>_*; copy the CSVs named below into profiles/ and run tools/reduce_pmc.py
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=$1
-CMD="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
+CMD=${NBK_PMC_CMD:-"python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"}   # NBK_PMC_CMD="python3 tools/fk_time.py" profiles the FK kernels
 run() {  # name, extra rocprofv3 args...
   name=$1; shift
   out=gpurun_out/${tag}_$name

@@ -70,12 +70,27 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
     ap.add_argument("--batch", type=int, default=1_000_000)
+    ap.add_argument("--also", default=None, help="tag of a second set of passes (tools/fk_time.py under NBK_PMC_CMD) whose kernels are merged in")
     a = ap.parse_args()
     p = lambda s: os.path.join(ROOT, "profiles", f"{a.tag}_pmc_{s}_counter_collection.csv")
     fetch, _, _ = read(p("fetch_size"))
     write, _, _ = read(p("write_size"))
     sq, sq_dur, grid = read(p("sq"))
     clk, clk_dur, _ = read(p("clk"))
+    if a.also:
+        p2 = lambda s: os.path.join(ROOT, "profiles", f"{a.also}_pmc_{s}_counter_collection.csv")
+        f2, _, _ = read(p2("fetch_size"))
+        w2, _, _ = read(p2("write_size"))
+        s2, s2_dur, g2 = read(p2("sq"))
+        for k in (f2 or {}):
+            if k not in fetch:
+                fetch[k] = f2[k]
+        for k in (w2 or {}):
+            if k not in write:
+                write[k] = w2[k]
+        for k in (s2 or {}):
+            if sq is not None and k not in sq:
+                sq[k], sq_dur[k], grid[k] = s2[k], s2_dur[k], g2[k]
     out = {"command": "rocprofv3 --kernel-trace --pmc <one counter set per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
            "units": "FETCH_SIZE / WRITE_SIZE are KiB per dispatch (mean over dispatches); gfx950 correction per "
                     "MI355X_MICROARCH.md: wide coalesced reads report 1/2 -> fetch_bytes = 2*FETCH_SIZE*1024",
