@@ -162,6 +162,7 @@ struct nbk_model {
     std::vector<int> h_cat, h_cls;
     std::vector<int> h_joint_qidx, h_joint_type, h_joint_kind;   // host copies for make_path
     std::vector<double> gjk_margins;   // (mA, mB) of every pair that can reach GJK: the host picks the narrowphase build per call
+    bool world_hulls = false;          // a world shape is a hull: k_broad_f32<S, true>
     bool gjk_any_hull = false;         // ... and whether one of them has a hull core (those always take the distance iteration)
     bool parked_ok;           // all robot cores of 64 configurations fit LDS (fused validity, distances, one-wave-per-edge)
     bool lds_broad_ok;        // the LDS broadphase k_broad fits this scene (else only the register broadphases are used)
@@ -2069,7 +2070,7 @@ __device__ unsigned long long g_broad_prof[8];
 #ifndef NBK_BF32_WAVES
 #define NBK_BF32_WAVES 5
 #endif
-template <int S>
+template <int S, bool WH>      // WH: the world holds hulls (scenes without them get a kernel without that branch: primitive scenes lost 8 us to it)
 __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                    uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
                                                    unsigned long long* __restrict__ q_count, unsigned long long* __restrict__ q_items,
@@ -2361,7 +2362,7 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
                         if (a < m.n_rshapes) NBK_ENQUEUE(cwv[a] < 0 && live, tab_wp[w * 16 + a]);
                 }
                 continue;
-            } else if (wk == K_HULL) {
+            } else if (WH && wk == K_HULL) {
                 // the box slot's form with the hull's local bounding box: candidate = bounding spheres (dd < wkey2) and the centre closer
                 // to that box than tc+ + rho + slack (a cull only: the box contains the hull); certain hit = the inscribed balls (dd < cert)
                 const float* ob = m.f_tab + m.f_wobb + 6 * w;
@@ -3609,6 +3610,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
         memcpy(&rs_local[12 * i], d->rshape_local + 12 * s, 12 * sizeof(double));
     }
     std::vector<int> ws_kind(W);
+    bool world_hulls = false;
     std::vector<double> ws_core(18 * (size_t)W);
     for (int w = 0; w < W; ++w) {
         double cc[6];
@@ -3621,6 +3623,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
             ws_hull[w] = h;
         }
         ws_kind[w] = kind;
+        world_hulls = world_hulls || kind == K_HULL;
         const double* T = d->wshape_pose + 12 * w;
         double* o = &ws_core[18 * w];
         o[0] = T[3]; o[1] = T[7]; o[2] = T[11];
@@ -4064,6 +4067,7 @@ int32_t nbk_model_create(const nbk_model_desc* d, nbk_model** out) {
     }
     M->gjk_margins = gjk_margins;
     M->gjk_any_hull = gjk_any_hull;
+    M->world_hulls = world_hulls;
     M->lds_broad_ok = lds_broad_ok;
     M->parked_ok = parked_ok;
     (void)hipGetDevice(&M->device);
@@ -4517,12 +4521,11 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
             if (internal) iw->ready = false;
             hipLaunchKernelGGL(k_zero_counters, dim3(1), dim3(NSUB), 0, st, count, flag_words, n_flag_words);
         }
-        if (use_reg && f32 && S <= 8)
-            hipLaunchKernelGGL(k_broad_f32<8>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
-        else if (use_reg && f32 && S <= 12)
-            hipLaunchKernelGGL(k_broad_f32<12>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
-        else if (use_reg && f32)
-            hipLaunchKernelGGL(k_broad_f32<16>, dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab);
+#define NBK_LAUNCH_BF32(S_, WH_) hipLaunchKernelGGL((k_broad_f32<S_, WH_>), dim3(nblk), dim3(WAVE), lds_f, st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub, ftab)
+        if (use_reg && f32 && S <= 8) { if (m->world_hulls) NBK_LAUNCH_BF32(8, true); else NBK_LAUNCH_BF32(8, false); }
+        else if (use_reg && f32 && S <= 12) { if (m->world_hulls) NBK_LAUNCH_BF32(12, true); else NBK_LAUNCH_BF32(12, false); }
+        else if (use_reg && f32) { if (m->world_hulls) NBK_LAUNCH_BF32(16, true); else NBK_LAUNCH_BF32(16, false); }
+#undef NBK_LAUNCH_BF32
         else if (use_reg && S <= 8)
             hipLaunchKernelGGL(k_broad_reg<8>, dim3(nblk), dim3(WAVE), broad_reg_lds(m, 8), st, m->d, es_tile, qt, nb, threshold, mb, my, count, items, cap_sub);
         else if (use_reg && S <= 12)
