@@ -341,6 +341,13 @@ struct PathArg { int len; int idx[NBK_MAX_JOINTS]; double local[12]; int col[NBK
 // LDS: the raw q slab (64*n_q doubles) and the output rows (64 * 17 doubles) share one region: every q
 // value is in a register before the first pose element is written, so 8.7 KB per wave is all it takes and
 // 4+ waves per SIMD stay resident to cover the HBM latency (the kernel is bandwidth-bound: 184 B per pose).
+// DQ (n_q <= 8): every lane loads its own q row straight into registers -- eight-byte loads at a 8 n_q-byte stride, the wave's
+// n_q instructions hit the same lines -- and a joint picks its value with a scalar switch; no LDS pass and no barrier before the sweep.
+NBK_DEV double pick8(const double (&v)[8], int i) {
+    switch (i) { case 0: return v[0]; case 1: return v[1]; case 2: return v[2]; case 3: return v[3];
+                 case 4: return v[4]; case 5: return v[5]; case 6: return v[6]; default: return v[7]; }
+}
+template <bool DQ>
 __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const double* __restrict__ q, int64_t B,
                                             const double* __restrict__ local_pose, double* __restrict__ T_out) {
     extern __shared__ double lds[];
@@ -348,7 +355,13 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nq = m.n_q;
     const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
-    {
+    double qv[8];
+    if constexpr (DQ) {
+        const int64_t br = (base + lane) < B ? (base + lane) : (B - 1);
+        const double* src = q + br * nq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = j < nq ? src[j] : 0.0;
+    } else {
         const int total = (int)rows * nq;
         const double* src = q + base * nq;
         if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
@@ -369,7 +382,8 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
         int i = 0;
         for (; i + 1 < path.len; i += 2) {
             const int k0 = path.idx[i], k1 = path.idx[i + 1];
-            const double q0 = myq[m.joint_qidx[k0]], q1 = myq[m.joint_qidx[k1]];
+            const double q0 = DQ ? pick8(qv, m.joint_qidx[k0]) : myq[m.joint_qidx[k0]];
+            const double q1 = DQ ? pick8(qv, m.joint_qidx[k1]) : myq[m.joint_qidx[k1]];
             Xf U;
             joint_apply(m, k0, T, q0, U);
             joint_apply(m, k1, U, q1, T);
@@ -377,7 +391,7 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
         if (i < path.len) {
             const int k = path.idx[i];
             Xf U;
-            joint_apply(m, k, T, myq[m.joint_qidx[k]], U);
+            joint_apply(m, k, T, DQ ? pick8(qv, m.joint_qidx[k]) : myq[m.joint_qidx[k]], U);
             T = U;
         }
     }
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(64) void k_fk(DevModel m, PathArg path, const doubl
         xf_mul(E, P.R, P.t, E2);
         E = E2;
     }
-    __syncthreads();                   // all q reads are done: the region is reused for the transposed poses
+    if constexpr (!DQ) __syncthreads();   // all q reads are done: the region is reused for the transposed poses
     // transpose through LDS (row stride 17 doubles: conflict-free ds_write_b64)
     double* row = lds + lane * 17;
 #pragma unroll
@@ -4152,10 +4166,11 @@ struct Options {
     long long pipe_tile;            // NBK_PIPE_TILE: configurations per tile of a pipelined batch (default 2^20)
     long long queue_budget;         // NBK_QUEUE_BUDGET: bytes the item queues of one tile may take (default 1 GiB); tests shrink it to force
                                     // the overflow path (k_validity_redo)
+    long long fk_lds_q;             // NBK_FK_LDS_Q=1: k_fk stages q in LDS also for n_q <= 8 (A/B switch)
 };
 static long long env_ll(const char* name, long long dflt) { const char* e = getenv(name); return e ? atoll(e) : dflt; }
 static Options g_opt = {env_ll("NBK_TWO_KERNEL_MIN_B", 1), env_ll("NBK_EDGE_BATCH_MIN_E", 1), env_ll("NBK_NO_REG_BROAD", 0),
-                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_PIPELINE_TILES", 1), env_ll("NBK_PIPE_TILE", 1ll << 20), env_ll("NBK_QUEUE_BUDGET", 1ll << 30)};
+                        env_ll("NBK_F64_BROAD", 0), env_ll("NBK_JAC_TWO_SWEEP", 0), env_ll("NBK_CLOSEST_BRUTE", 0), env_ll("NBK_NARROW_PARTS_MAX", 16), env_ll("NBK_PIPELINE_TILES", 1), env_ll("NBK_PIPE_TILE", 1ll << 20), env_ll("NBK_QUEUE_BUDGET", 1ll << 30), env_ll("NBK_FK_LDS_Q", 0)};
 
 // diagnostic (not part of include/nbk.h): set one of the switches above by name; returns NBK_ERR_INVALID for an unknown name
 extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
@@ -4163,7 +4178,7 @@ extern "C" int32_t nbk_debug_set_option(const char* name, int64_t value) {
     struct { const char* n; long long* v; } tab[] = {
         {"two_kernel_min_b", &g_opt.two_kernel_min_b}, {"edge_batch_min_e", &g_opt.edge_batch_min_e}, {"no_reg_broad", &g_opt.no_reg_broad},
         {"f64_broad", &g_opt.f64_broad}, {"jac_two_sweep", &g_opt.jac_two_sweep}, {"closest_brute", &g_opt.closest_brute},
-        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}, {"pipeline_tiles", &g_opt.pipeline_tiles}, {"pipe_tile", &g_opt.pipe_tile}};
+        {"narrow_parts_max", &g_opt.narrow_parts_max}, {"queue_budget", &g_opt.queue_budget}, {"pipeline_tiles", &g_opt.pipeline_tiles}, {"pipe_tile", &g_opt.pipe_tile}, {"fk_lds_q", &g_opt.fk_lds_q}};
     for (auto& t : tab) if (strcmp(t.n, name) == 0) { *t.v = (long long)value; return NBK_OK; }
     return NBK_ERR_INVALID;
 }
@@ -4196,7 +4211,8 @@ int32_t nbk_fk_batch(const nbk_model* m, const double* q, int64_t B, const int32
     if (st != NBK_OK) return st;
     if (B == 0) return NBK_OK;
     const size_t lds = sizeof(double) * WAVE * ((size_t)(m->n_q > 17 ? m->n_q : 17));
-    hipLaunchKernelGGL(k_fk, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, local_pose, T_out);
+    if (m->n_q <= 8 && !g_opt.fk_lds_q) hipLaunchKernelGGL(k_fk<true>, dim3(blocks_for(B)), dim3(WAVE), sizeof(double) * WAVE * 17, (hipStream_t)stream, m->d, pa, q, B, local_pose, T_out);
+    else hipLaunchKernelGGL(k_fk<false>, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, local_pose, T_out);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }

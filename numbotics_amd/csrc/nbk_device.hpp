@@ -821,7 +821,18 @@ __device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc) 
 #define EPA_MAXV (4 + EPA_MAXIT)
 #define EPA_MAXF (4 + 2 * EPA_MAXIT + 8)
 #define EPA_MAXE 64
-struct Epa { double v[EPA_MAXV][3]; int nv; short f[EPA_MAXF][3]; double fn[EPA_MAXF][3]; double fd[EPA_MAXF]; int nf; double ref[3]; };   // f[q][0] < 0: a free slot
+// The polytope lives in per-lane scratch (4 KB), where a dependent load costs most of a microsecond: which faces are alive is a
+// bit mask in registers (no flag loads, the lowest free slot is a bit scan), a face's three vertex indices are one packed word, the
+// scans over the faces load unconditionally so that the unrolled trips overlap their loads, and the horizon is built from a
+// visibility mask in ascending face order -- the order, the arithmetic and therefore every result are those of the oracle's loops.
+struct Epa { double v[EPA_MAXV][3]; double fn[EPA_MAXF][3]; double fd[EPA_MAXF]; int f[EPA_MAXF]; double ref[3]; int nv, nf;
+             unsigned long long alive0; unsigned alive1; };
+static_assert(EPA_MAXF <= 96 && EPA_MAXV <= 255, "alive masks / packed vertex indices");
+NBK_DEV bool epa_alive(const Epa& e, int q) { return q < 64 ? ((e.alive0 >> q) & 1ull) != 0ull : ((e.alive1 >> (q - 64)) & 1u) != 0u; }
+NBK_DEV void epa_set_alive(Epa& e, int q, bool on) {
+    if (q < 64) { const unsigned long long b = 1ull << q; e.alive0 = on ? (e.alive0 | b) : (e.alive0 & ~b); }
+    else { const unsigned b = 1u << (q - 64); e.alive1 = on ? (e.alive1 | b) : (e.alive1 & ~b); }
+}
 
 NBK_DEV bool epa_face_plane(const Epa& e, int i, int j, int k, double* n, double& d) {
     double ab[3], ac[3], c[3];
@@ -839,10 +850,20 @@ NBK_DEV bool epa_add_face(Epa& e, int i, int j, int k) {
     if (!epa_face_plane(e, i, j, k, n, d)) return false;
     sub3(e.v[i], e.ref, r);
     if (dot3(n, r) < 0.0) { const int t = j; j = k; k = t; d = -d; n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    // the lowest free slot below nf, else a new one
     int slot = -1;
-    for (int q = 0; q < e.nf; ++q) if (e.f[q][0] < 0) { slot = q; break; }
+    {
+        const unsigned long long m0 = e.nf >= 64 ? ~0ull : ((1ull << e.nf) - 1ull);
+        const unsigned long long free0 = ~e.alive0 & m0;
+        if (free0 != 0ull) slot = __builtin_ctzll(free0);
+        else if (e.nf > 64) {
+            const unsigned free1 = ~e.alive1 & ((1u << (e.nf - 64)) - 1u);
+            if (free1 != 0u) slot = 64 + __builtin_ctz(free1);
+        }
+    }
     if (slot < 0) { if (e.nf >= EPA_MAXF) return false; slot = e.nf++; }
-    e.f[slot][0] = (short)i; e.f[slot][1] = (short)j; e.f[slot][2] = (short)k; e.fd[slot] = d;
+    epa_set_alive(e, slot, true);
+    e.f[slot] = i | (j << 8) | (k << 16); e.fd[slot] = d;
     e.fn[slot][0] = n[0]; e.fn[slot][1] = n[1]; e.fn[slot][2] = n[2];
     return true;
 }
@@ -885,15 +906,21 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) e.ref[c] = 0.25 * (((e.v[0][c] + e.v[1][c]) + e.v[2][c]) + e.v[3][c]);
-    e.nv = 4; e.nf = 0;
+    e.nv = 4; e.nf = 0; e.alive0 = 0ull; e.alive1 = 0u;
     if (!epa_add_face(e, 0, 1, 2) || !epa_add_face(e, 0, 1, 3) || !epa_add_face(e, 0, 2, 3) || !epa_add_face(e, 1, 2, 3)) return false;
     double best_up = NBK_INF, best_n[3] = {1.0, 0.0, 0.0};
     for (int it = 0; it < EPA_MAXIT; ++it) {
+        // the alive face with the smallest plane distance, the first of equals
         int bf = -1;
-        for (int q = 0; q < e.nf; ++q) if (e.f[q][0] >= 0 && (bf < 0 || e.fd[q] < e.fd[bf])) bf = q;
+        double bd = 0.0;
+#pragma unroll 4
+        for (int q = 0; q < e.nf; ++q) {
+            const double dq = e.fd[q];
+            if (epa_alive(e, q) && (bf < 0 || dq < bd)) { bf = q; bd = dq; }
+        }
         if (bf < 0) break;
         const double n[3] = {e.fn[bf][0], e.fn[bf][1], e.fn[bf][2]};
-        const double d = e.fd[bf];
+        const double d = bd;
         double w[3];
         mink_support(A, Bc, n, w);
         const double dw = dot3(n, w);
@@ -902,26 +929,40 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
         if (e.nv >= EPA_MAXV) break;
         const int wi = e.nv++;
         copy3(w, e.v[wi]);
-        short edges[EPA_MAXE][2];
+        // the faces that see w
+        unsigned long long vis0 = 0ull;
+        unsigned vis1 = 0u;
+#pragma unroll 2
+        for (int q = 0; q < e.nf; ++q) {
+            const double fq[3] = {e.fn[q][0], e.fn[q][1], e.fn[q][2]};
+            const double sq = dot3(fq, w) - e.fd[q];
+            if (epa_alive(e, q) && !(sq <= 0.0)) { if (q < 64) vis0 |= 1ull << q; else vis1 |= 1u << (q - 64); }
+        }
+        e.alive0 &= ~vis0; e.alive1 &= ~vis1;
+        // their edges, in ascending face order; an edge met twice is interior
+        int edges[EPA_MAXE];
         int ne = 0;
         bool overflow = false;
-        for (int q = 0; q < e.nf; ++q) {
-            if (e.f[q][0] < 0) continue;
-            if (dot3(e.fn[q], w) - e.fd[q] <= 0.0) continue;
-            const int fv[3] = {e.f[q][0], e.f[q][1], e.f[q][2]};
-            e.f[q][0] = -1;
+        while (vis0 != 0ull || vis1 != 0u) {
+            int q;
+            if (vis0 != 0ull) { q = __builtin_ctzll(vis0); vis0 &= vis0 - 1ull; }
+            else { q = 64 + __builtin_ctz(vis1); vis1 &= vis1 - 1u; }
+            const int fw = e.f[q];
+            const int fv[3] = {fw & 255, (fw >> 8) & 255, (fw >> 16) & 255};
+#pragma unroll
             for (int s3 = 0; s3 < 3; ++s3) {
                 const int a = fv[s3], b = fv[(s3 + 1) % 3];
+                const int ab = (a << 8) | b, ba = (b << 8) | a;
                 int found = -1;
-                for (int t = 0; t < ne; ++t) if ((edges[t][0] == b && edges[t][1] == a) || (edges[t][0] == a && edges[t][1] == b)) { found = t; break; }
-                if (found >= 0) { edges[found][0] = edges[ne - 1][0]; edges[found][1] = edges[ne - 1][1]; --ne; }
-                else if (ne < EPA_MAXE) { edges[ne][0] = (short)a; edges[ne][1] = (short)b; ++ne; }
+                for (int t = 0; t < ne; ++t) { const int et = edges[t]; if (et == ba || et == ab) { found = t; break; } }
+                if (found >= 0) { edges[found] = edges[ne - 1]; --ne; }
+                else if (ne < EPA_MAXE) { edges[ne] = ab; ++ne; }
                 else overflow = true;
             }
         }
         if (ne < 3 || overflow) break;
         bool bad = false;
-        for (int t = 0; t < ne; ++t) if (!epa_add_face(e, edges[t][0], edges[t][1], wi)) { bad = true; break; }
+        for (int t = 0; t < ne; ++t) { const int et = edges[t]; if (!epa_add_face(e, et >> 8, et & 255, wi)) { bad = true; break; } }
         if (bad) break;
     }
     if (!(best_up < NBK_INF)) return false;
