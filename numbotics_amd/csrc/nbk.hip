@@ -546,7 +546,11 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     const int nq = m.n_q;
     const int64_t rows = (B - base) < WAVE ? (B - base) : WAVE;
-    {
+    // (mode bit 8: stage q through LDS as the general kernel does -- the A/B switch NBK_FK_LDS_Q; otherwise every lane loads its own
+    // values straight from its row: the wave's loads hit the same lines, and there is no LDS pass or barrier before the sweep)
+    const bool stage = (mode & 256) != 0;
+    mode &= 255;
+    if (stage) {
         const int total = (int)rows * nq;
         const double* src = q + base * nq;
         if (rows == WAVE && ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && (total % 2 == 0)) {
@@ -559,7 +563,7 @@ __global__ __launch_bounds__(64) void k_jacobian_reg(DevModel m, PathArg path, c
         }
         __syncthreads();
     }
-    const double* myq = lds + lane * nq;
+    const double* myq = stage ? lds + lane * nq : q + ((base + lane) < B ? (base + lane) : (B - 1)) * nq;
     double Wx[NJ][3], Ox[NJ][3];
     Xf T;
     xf_from12(m.base_pose, T);
@@ -4296,7 +4300,7 @@ int32_t nbk_jacobian_batch(const nbk_model* m, const double* q, int64_t B, const
         const int stride = (6 * m->n_q) | 1;
         const size_t lds_q = (size_t)WAVE * (size_t)m->n_q, lds_rows = (size_t)JAC_ROWS * (size_t)stride;     // the rows reuse the q area
         const size_t lds = sizeof(double) * (lds_q > lds_rows ? lds_q : lds_rows);
-        hipLaunchKernelGGL(k_jacobian_reg<8>, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, mode, pose, J_out);
+        hipLaunchKernelGGL(k_jacobian_reg<8>, dim3(blocks_for(B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, pa, q, B, mode | (g_opt.fk_lds_q ? 256 : 0), pose, J_out);
         NBK_HIP(hipGetLastError());
         return NBK_OK;
     }
