@@ -34,7 +34,7 @@ VALU_CYCLES_DEFAULT = 4
 N_CU = 256
 
 KERNELS = {"k_broad_f32": "nbk::k_broad_f32", "k_broad_reg": "nbk::k_broad_reg", "k_broad": "nbk::k_broad(", "k_narrow": "nbk::k_narrow",
-           "k_fk_frames": "nbk::k_fk_frames", "k_fk": "nbk::k_fk(", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
+           "k_fk_frames": "nbk::k_fk_frames", "k_fk": "nbk::k_fk<", "k_validity": "nbk::k_validity", "k_jacobian": "nbk::k_jacobian"}
 
 
 def short(name):
