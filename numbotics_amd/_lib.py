@@ -106,7 +106,7 @@ def load():
 # tuning / diagnostic switches of the library (process-wide; seeded once from the NBK_* environment variables when the library
 # is loaded, never read again): name -> default.  None of them changes a result.
 DEBUG_OPTIONS = {"two_kernel_min_b": 1, "edge_batch_min_e": 1, "no_reg_broad": 0, "f64_broad": 0, "jac_two_sweep": 0,
-                 "closest_brute": 0, "narrow_parts_max": 16, "queue_budget": 1 << 30, "pipeline_tiles": 1, "pipe_tile": 1 << 20}
+                 "closest_brute": 0, "narrow_parts_max": 16, "queue_budget": 1 << 30, "pipeline_tiles": 1, "pipe_tile": 1 << 20, "fk_lds_q": 0}
 
 
 def set_debug_option(name: str, value: int):

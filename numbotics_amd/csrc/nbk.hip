@@ -3174,6 +3174,8 @@ __global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __rest
     unsigned long long* lds_best = reinterpret_cast<unsigned long long*>(lds_res + CQ_CAP);   // [64]
     unsigned* lds_arg = reinterpret_cast<unsigned*>(lds_best + WAVE);                   // [64]
     unsigned* queue = lds_arg + WAVE;                                                    // [CQ_CAP]
+    unsigned short* elist = reinterpret_cast<unsigned short*>(queue + CQ_CAP);                                                    // [CQ_CAP] queue slots (of pass 2) whose depth needs EPA
+    constexpr unsigned CQ_DEFER = 0x40000000u;                                           // queue item flag: provisional (axis-family) depth
     stage_q(q, base, B, m.n_q, lds_s, lds_q, lane);
     const int64_t b = base + lane;
     const bool active = b < B;
@@ -3199,7 +3201,8 @@ __global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __rest
     }
     lds_best[lane] = ~0ull;
     lds_arg[lane] = 0x7FFFFFFFu;
-    // round 1 (dense, one item per lane): the exact distance of that most promising pair tightens U a lot
+    // round 1 (dense, one item per lane): the exact distance of that most promising pair -- EPA inline where the cores overlap: its
+    // depth is what makes U tight for a colliding configuration -- tightens U a lot
     queue[lane] = active ? (((unsigned)p1 << 6) | (unsigned)lane) : 0xFFFFFFFFu;
     {
         double d1 = NBK_INF;
@@ -3259,7 +3262,45 @@ __global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __rest
             Core A, Bc;
             load_core_any(m, lds_s, a, src, A);
             load_core_any(m, lds_s, bb < m.n_rshapes ? bb : ~(bb - m.n_rshapes), src, Bc);
-            const double d = cores_distance<false>(A, Bc, nullptr);
+            double fam = -1.0;
+            const double d = cores_distance<false, true>(A, Bc, nullptr, &fam);
+            lds_res[i] = d;
+            if (fam >= 0.0) queue[i] = item | CQ_DEFER;
+            else atomicMin(&lds_best[src], orderable(d));
+        }
+    }
+    __syncthreads();
+    // the deferred items, compacted; one whose provisional value (a lower bound) is already above its lane's best cannot be the
+    // minimum nor tie with it and is dropped -- the best only decreases, so a stale read errs on the side of running EPA
+    int en = 0;
+    for (int i0 = 0; i0 < qn; i0 += WAVE) {
+        const int i = i0 + lane;
+        bool need = false;
+        if (i < qn) {
+            const unsigned item = queue[i];
+            need = item != 0xFFFFFFFFu && (item & CQ_DEFER) != 0u && !(orderable(lds_res[i]) > lds_best[(int)(item & 63u)]);
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(need);
+        if (need) elist[en + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)i;
+        en += __builtin_popcountll(bal);
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < en; j0 += WAVE) {
+        const int j = j0 + lane;
+        if (j < en) {
+            const int i = (int)elist[j];
+            const unsigned item = queue[i] & ~CQ_DEFER;
+            const int src = (int)(item & 63u), p = (int)(item >> 6);
+            const int a = m.pair_a[p], bb = m.pair_b[p];
+            Core A, Bc;
+            load_core_any(m, lds_s, a, src, A);
+            load_core_any(m, lds_s, bb < m.n_rshapes ? bb : ~(bb - m.n_rshapes), src, Bc);
+            // overlap_depth_exact, in two steps: the family value again (4 KB of LDS to keep it cost a resident workgroup on the
+            // benchmark arm), then EPA's if it is smaller
+            double n[3], o[4];
+            double depth = overlap_depth(A, Bc, n);
+            if (epa_depth_copy(A, Bc, o) && o[0] < depth) depth = o[0];
+            const double d = ((-depth) - A.margin) - Bc.margin;
             lds_res[i] = d;
             atomicMin(&lds_best[src], orderable(d));
         }
@@ -3268,7 +3309,7 @@ __global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __rest
     for (int i0 = 0; i0 < qn; i0 += WAVE) {
         const int i = i0 + lane;
         if (i < qn) {
-            const unsigned item = queue[i];
+            const unsigned item = queue[i] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (queue[i] & ~CQ_DEFER);
             if (item != 0xFFFFFFFFu) {
                 const int src = (int)(item & 63u), p = (int)(item >> 6);
                 if (orderable(lds_res[i]) == lds_best[src]) atomicMin(&lds_arg[src], (unsigned)m.pair_user[p]);
@@ -4694,13 +4735,14 @@ int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double
     NBK_DEVICE(m);
     if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0) return NBK_OK;
-    if (g_opt.closest_brute)
+    // branch-and-bound needs its result / best / argmin / queue / EPA-list arrays next to the parked cores; a robot that leaves no room
+    // for them gets every pair evaluated (same result)
+    const size_t closest_lds = collide_lds(m) - VALIDITY_LDS_EXTRA + sizeof(double) * CQ_CAP + 8 * WAVE + 4 * WAVE + 4 * CQ_CAP + 2 * CQ_CAP;
+    if (g_opt.closest_brute || closest_lds > 160 * 1024)
         hipLaunchKernelGGL(k_distances<0>, dim3(blocks_for(B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, min_dist,
                            argmin, (double*)nullptr);
     else
-        hipLaunchKernelGGL(k_closest, dim3(blocks_for(B)), dim3(WAVE),
-                           collide_lds(m) - VALIDITY_LDS_EXTRA + sizeof(double) * CQ_CAP + 8 * WAVE + 4 * WAVE + 4 * CQ_CAP,
-                           (hipStream_t)stream, m->d, q, B, min_dist, argmin);
+        hipLaunchKernelGGL(k_closest, dim3(blocks_for(B)), dim3(WAVE), closest_lds, (hipStream_t)stream, m->d, q, B, min_dist, argmin);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
 }

@@ -107,6 +107,23 @@ def test_jacobian_bitwise_and_golden(kinova, g3, golden_meta, torch_cuda):
     assert np.array_equal(arm.jacobian(q[:4], "base_link"), np.zeros((4, 6, 7)))  # arm.py:455-457
 
 
+def test_fk_and_jacobian_q_paths_agree(kinova, g3, torch_cuda):
+    """k_fk / k_jacobian_reg read q straight into registers for n_q <= 8; the LDS-staged form (robots beyond 8 DoF, or the
+    ``fk_lds_q`` switch) must give the same bits, ragged block tails included."""
+    from numbotics_amd._lib import debug_option
+    arm, chain, _ = kinova
+    orc = Oracle(arm._kin)
+    q = g3["g3_q"]
+    for B in (1, 63, 64, 65, 1000):
+        T, J = arm.forward_kinematics(q[:B], "tool_frame"), arm.jacobian(q[:B], "tool_frame")
+        with debug_option("fk_lds_q", 1):
+            T2, J2 = arm.forward_kinematics(q[:B], "tool_frame"), arm.jacobian(q[:B], "tool_frame")
+        assert_bitwise(T, T2, f"fk q paths B={B}")
+        assert_bitwise(J, J2, f"jacobian q paths B={B}")
+        assert_bitwise(T, orc.fk(q[:B], "tool_frame"), f"fk B={B}")
+        assert_bitwise(J, orc.jacobian(q[:B], "tool_frame"), f"jacobian B={B}")
+
+
 @pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("scene", ["c1", "c2", "c3"])
 def test_validity_mask_bitwise(fresh_world, scene, margins, torch_cuda):
