@@ -541,7 +541,7 @@ def main():
             parity_ok = False
 
     # ---- CPU baseline: the oracle (port) on this box's host cores, bounded sample ---------------------
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:            # (rank 0 at N = 1 only, as the bench contract says)
         # the box's CPU share for one GPU is 16 cores (gpurun guidance); never more threads than allowed CPUs
         cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
         n_s = min(B, 1_000_000)
