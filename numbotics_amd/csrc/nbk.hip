@@ -3037,7 +3037,7 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
                 load_core_any(m, lds_s, a, src, A);
                 load_core_any(m, lds_s, bb < m.n_rshapes ? bb : ~(bb - m.n_rshapes), src, Bc);
                 double o[4];
-                if (epa_depth_copy(A, Bc, o) && o[0] < fam) {
+                if (epa_depth_copy(A, Bc, o, 0, 0.0) == 1 && o[0] < fam) {
                     // the record of cores_distance's overlap branch, with EPA's depth and direction
                     const double n[3] = {o[1], o[2], o[3]};
                     const double dc = -o[0];
@@ -3299,7 +3299,7 @@ __global__ __launch_bounds__(64) void k_closest(DevModel m, const double* __rest
             // benchmark arm), then EPA's if it is smaller
             double n[3], o[4];
             double depth = overlap_depth(A, Bc, n);
-            if (epa_depth_copy(A, Bc, o) && o[0] < depth) depth = o[0];
+            if (epa_depth_copy(A, Bc, o, 0, 0.0) == 1 && o[0] < depth) depth = o[0];
             const double d = ((-depth) - A.margin) - Bc.margin;
             lds_res[i] = d;
             atomicMin(&lds_best[src], orderable(d));

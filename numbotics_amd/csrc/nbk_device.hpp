@@ -515,8 +515,8 @@ template <bool LDSV = false>
 NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal);
 // the predicate's use of it (negative tc, penetrating cores) goes through a real call on COPIES of the cores: inlined into the
 // GJK loop its fifteen-axis family drove k_narrow / k_narrow_pred to 600+ spilled VGPRs once the cores lived in registers
-__device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc);
-NBK_DEV double overlap_depth_call(const Core& A, const Core& Bc) { return overlap_depth_copy(A, Bc); }
+__device__ __attribute__((noinline)) bool overlap_deeper_copy(Core A, Core Bc, double x);
+NBK_DEV bool overlap_deeper_call(const Core& A, const Core& Bc, double x) { return overlap_deeper_copy(A, Bc, x); }
 
 // GJK predicate: dist(coreA, coreB) < tc ?  Same iteration, but it returns as soon as the support-plane
 // lower bound reaches tc (free) or the simplex point drops below tc (colliding).
@@ -571,7 +571,7 @@ NBK_DEV int gjk_pred_step(GjkPred& g, const Core& A, const Core& Bc, double tc) 
                 else {
                     if (POSITIVE || tc >= 0.0) return 2;
                     if constexpr (!POSITIVE) {
-                        return (-overlap_depth_call(A, Bc) < tc) ? 2 : 1;
+                        return overlap_deeper_call(A, Bc, -tc) ? 2 : 1;
                     }
                 }
             } else if (st == 2) finish = true;
@@ -798,19 +798,25 @@ NBK_DEV double overlap_depth(const Core& A, const Core& Bc, double* normal) {
     return best;
 }
 
-__device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double* out);
-__device__ __attribute__((noinline)) double overlap_depth_copy(Core A, Core Bc) {
+__device__ __attribute__((noinline)) int epa_depth_copy(Core A, Core Bc, double* out, int decide, double x);
+// is the exact depth of two overlapping cores larger than x (= -tc > 0: the predicate at a negative contact threshold)?  The family's
+// value is an upper bound (not deeper: done) and exact without a cylinder / hull core; EPA stops at its first certain answer
+// (oracle: overlap_deeper_than)
+__device__ __attribute__((noinline)) bool overlap_deeper_copy(Core A, Core Bc, double x) {
     double nrm[3];
-    double depth;
+    double fam;
     const bool lds_a = A.rad > 0.0 && A.kind == K_HULL, lds_b = Bc.rad > 0.0 && Bc.kind == K_HULL;
-    if (lds_a || lds_b) depth = overlap_depth<true>(A, Bc, nrm);
-    else depth = overlap_depth<false>(A, Bc, nrm);
-    if (A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL) {
-        // (hull cores staged in LDS keep their LDS byte address in `rad`: the support routine ignores it)
-        double o[4];
-        if (epa_depth_copy(A, Bc, o) && o[0] < depth) depth = o[0];
-    }
-    return depth;
+    if (lds_a || lds_b) fam = overlap_depth<true>(A, Bc, nrm);
+    else fam = overlap_depth<false>(A, Bc, nrm);
+    if (!(fam > x)) return false;
+    if (!(A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL)) return true;
+    // (hull cores staged in LDS keep their LDS byte address in `rad`: the support routine ignores it)
+    double o[4];
+    const int r = epa_depth_copy(A, Bc, o, 1, x);
+    if (r == 2) return true;
+    if (r == 3) return false;
+    if (r == 1) return o[0] > x;
+    return true;                       // no answer from EPA: the family's value stands
 }
 
 // ---- exact penetration depth of overlapping cores with a cylinder or a hull: EPA (mirrors epa_depth of the oracle line by line:
@@ -834,17 +840,18 @@ NBK_DEV void epa_set_alive(Epa& e, int q, bool on) {
     else { const unsigned b = 1u << (q - 64); e.alive1 = on ? (e.alive1 | b) : (e.alive1 & ~b); }
 }
 
-NBK_DEV bool epa_face_plane(const Epa& e, int i, int j, int k, double* n, double& d) {
+NBK_DEV bool epa_plane_of(const double* vi, const double* vj, const double* vk, double* n, double& d) {
     double ab[3], ac[3], c[3];
-    sub3(e.v[j], e.v[i], ab); sub3(e.v[k], e.v[i], ac);
+    sub3(vj, vi, ab); sub3(vk, vi, ac);
     cross3(ab, ac, c);
     const double cc = dot3(c, c);
     if (!(cc > 1e-60)) return false;
     const double inv = 1.0 / nbk_sqrt(cc);
     n[0] = c[0] * inv; n[1] = c[1] * inv; n[2] = c[2] * inv;
-    d = dot3(n, e.v[i]);
+    d = dot3(n, vi);
     return true;
 }
+NBK_DEV bool epa_face_plane(const Epa& e, int i, int j, int k, double* n, double& d) { return epa_plane_of(e.v[i], e.v[j], e.v[k], n, d); }
 NBK_DEV bool epa_add_face(Epa& e, int i, int j, int k) {
     double n[3], d, r[3];
     if (!epa_face_plane(e, i, j, k, n, d)) return false;
@@ -867,18 +874,19 @@ NBK_DEV bool epa_add_face(Epa& e, int i, int j, int k) {
     e.fn[slot][0] = n[0]; e.fn[slot][1] = n[1]; e.fn[slot][2] = n[2];
     return true;
 }
-// out[0] = depth, out[1..3] = direction from B to A; false: no answer (the caller keeps the axis-family value)
-__device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double* out) {
-    Epa e;
+// 1: out[0] = depth, out[1..3] = direction from B to A; 0: no answer (the caller keeps the axis-family value); with `decide` also
+// 2: certainly deeper than x (the nearest face of the inner polytope is farther than x), 3: certainly not (a support plane within x)
+__device__ __attribute__((noinline)) int epa_depth_copy(Core A, Core Bc, double* out, int decide, double x) {
+    double sv[4][3];                  // the start tetrahedron, in registers until the polytope is needed
     {
         const double D0[3] = {0.5345224838248488, -0.2672612419124244, 0.8017837257372732};
         const double nD0[3] = {-D0[0], -D0[1], -D0[2]};
-        mink_support(A, Bc, D0, e.v[0]);
-        mink_support(A, Bc, nD0, e.v[1]);
+        mink_support(A, Bc, D0, sv[0]);
+        mink_support(A, Bc, nD0, sv[1]);
         double e1[3];
-        sub3(e.v[1], e.v[0], e1);
+        sub3(sv[1], sv[0], e1);
         const double l1 = dot3(e1, e1);
-        if (!(l1 > 1e-30)) return false;
+        if (!(l1 > 1e-30)) return 0;
         const double ax = __builtin_fabs(e1[0]), ay = __builtin_fabs(e1[1]), az = __builtin_fabs(e1[2]);
         double a[3] = {0.0, 0.0, 0.0};
         if (ax <= ay && ax <= az) a[0] = 1.0; else if (ay <= az) a[1] = 1.0; else a[2] = 1.0;
@@ -887,27 +895,30 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
         nn2[0] = -n2[0]; nn2[1] = -n2[1]; nn2[2] = -n2[2];
         mink_support(A, Bc, n2, pa2);
         mink_support(A, Bc, nn2, pb2);
-        sub3(pa2, e.v[0], ra); sub3(pb2, e.v[0], rb);
+        sub3(pa2, sv[0], ra); sub3(pb2, sv[0], rb);
         cross3(e1, ra, ca); cross3(e1, rb, cb);
         const bool use_a = dot3(ca, ca) >= dot3(cb, cb);
-        copy3(use_a ? pa2 : pb2, e.v[2]);
+        copy3(use_a ? pa2 : pb2, sv[2]);
         double n3[3], nn3[3], pa3[3], pb3[3];
         copy3(use_a ? ca : cb, n3);
         const double l3 = dot3(n3, n3);
-        if (!(l3 > 1e-24 * l1 * l1)) return false;
+        if (!(l3 > 1e-24 * l1 * l1)) return 0;
         nn3[0] = -n3[0]; nn3[1] = -n3[1]; nn3[2] = -n3[2];
         mink_support(A, Bc, n3, pa3);
         mink_support(A, Bc, nn3, pb3);
-        sub3(pa3, e.v[0], ra); sub3(pb3, e.v[0], rb);
+        sub3(pa3, sv[0], ra); sub3(pb3, sv[0], rb);
         const double ha = __builtin_fabs(dot3(n3, ra)), hb = __builtin_fabs(dot3(n3, rb));
-        copy3(ha >= hb ? pa3 : pb3, e.v[3]);
+        copy3(ha >= hb ? pa3 : pb3, sv[3]);
         const double hh = ha >= hb ? ha : hb;
-        if (!(hh * hh > 1e-24 * l3 * l1)) return false;
+        if (!(hh * hh > 1e-24 * l3 * l1)) return 0;
     }
+    Epa e;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) e.ref[c] = 0.25 * (((e.v[0][c] + e.v[1][c]) + e.v[2][c]) + e.v[3][c]);
+    for (int i = 0; i < 4; ++i) { e.v[i][0] = sv[i][0]; e.v[i][1] = sv[i][1]; e.v[i][2] = sv[i][2]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e.ref[c] = 0.25 * (((sv[0][c] + sv[1][c]) + sv[2][c]) + sv[3][c]);
     e.nv = 4; e.nf = 0; e.alive0 = 0ull; e.alive1 = 0u;
-    if (!epa_add_face(e, 0, 1, 2) || !epa_add_face(e, 0, 1, 3) || !epa_add_face(e, 0, 2, 3) || !epa_add_face(e, 1, 2, 3)) return false;
+    if (!epa_add_face(e, 0, 1, 2) || !epa_add_face(e, 0, 1, 3) || !epa_add_face(e, 0, 2, 3) || !epa_add_face(e, 1, 2, 3)) return 0;
     double best_up = NBK_INF, best_n[3] = {1.0, 0.0, 0.0};
     for (int it = 0; it < EPA_MAXIT; ++it) {
         // the alive face with the smallest plane distance, the first of equals
@@ -921,10 +932,12 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
         if (bf < 0) break;
         const double n[3] = {e.fn[bf][0], e.fn[bf][1], e.fn[bf][2]};
         const double d = bd;
+        if (decide && d > x) return 2;
         double w[3];
         mink_support(A, Bc, n, w);
         const double dw = dot3(n, w);
         if (dw < best_up) { best_up = dw; best_n[0] = n[0]; best_n[1] = n[1]; best_n[2] = n[2]; }
+        if (decide && best_up <= x) return 3;
         if (dw - d <= EPA_TOL * (1.0 + __builtin_fabs(dw))) break;
         if (e.nv >= EPA_MAXV) break;
         const int wi = e.nv++;
@@ -965,10 +978,10 @@ __device__ __attribute__((noinline)) bool epa_depth_copy(Core A, Core Bc, double
         for (int t = 0; t < ne; ++t) { const int et = edges[t]; if (!epa_add_face(e, et >> 8, et & 255, wi)) { bad = true; break; } }
         if (bad) break;
     }
-    if (!(best_up < NBK_INF)) return false;
+    if (!(best_up < NBK_INF)) return 0;
     out[0] = best_up > 0.0 ? best_up : 0.0;
     out[1] = -best_n[0]; out[2] = -best_n[1]; out[3] = -best_n[2];
-    return true;
+    return 1;
 }
 // depth and direction (from B to A) of two overlapping cores: the axis family, tightened by EPA where the family is only a bound
 template <bool LDSV = false>
@@ -976,7 +989,7 @@ NBK_DEV double overlap_depth_exact(const Core& A, const Core& Bc, double* normal
     double depth = overlap_depth<LDSV>(A, Bc, normal);
     if (A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL) {
         double o[4];
-        if (epa_depth_copy(A, Bc, o) && o[0] < depth) { depth = o[0]; normal[0] = o[1]; normal[1] = o[2]; normal[2] = o[3]; }
+        if (epa_depth_copy(A, Bc, o, 0, 0.0) == 1 && o[0] < depth) { depth = o[0]; normal[0] = o[1]; normal[1] = o[2]; normal[2] = o[3]; }
     }
     return depth;
 }

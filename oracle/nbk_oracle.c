@@ -677,6 +677,7 @@ static int gjk_cores(const core_t *A, const core_t *Bc, double *pa, double *pb, 
 
 static double overlap_depth(const core_t *A, const core_t *Bc, double *normal);
 static double overlap_depth_exact(const core_t *A, const core_t *Bc, double *normal);
+static int overlap_deeper_than(const core_t *A, const core_t *Bc, double x);
 
 /* GJK predicate: is dist(coreA, coreB) < tc ?  Same iteration as gjk_cores, but it stops as soon as the
  * support-plane lower bound reaches tc (free) or the simplex point drops below tc (colliding). */
@@ -722,8 +723,7 @@ static int gjk_collides_it(const core_t *A, const core_t *Bc, double tc, int *it
         if (st == 1) {
             if (sep) break;
             if (tc >= 0.0) return 1;
-            double nrm[3];
-            return -overlap_depth_exact(A, Bc, nrm) < tc;
+            return overlap_deeper_than(A, Bc, -tc);
         }
         if (st == 2) break;
         if (tc > 0.0 && vv_prev < tc2) return 1;
@@ -1161,7 +1161,11 @@ static int epa_add_face(epa_t *e, int i, int j, int k) {
     return 1;
 }
 static long long g_epa_calls = 0, g_epa_fail = 0, g_epa_iters = 0;
-static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *normal) {
+/* returns 0: no answer; 1: *depth / normal valid.  decide != 0 (the predicate at a negative contact threshold asks "deeper than x?",
+ * x > 0): the loop also stops as soon as the answer is certain -- 2: the nearest face of the inner polytope is farther than x from the
+ * origin (origin inside, depth >= d > x); 3: a support plane at most x away has been seen (depth <= n.w <= x) -- and kernels and
+ * oracle stop at the same iteration, so the verdict is this function's by definition */
+static int epa_run(const core_t *A, const core_t *Bc, double *depth, double *normal, int decide, double x) {
     __atomic_add_fetch(&g_epa_calls, 1, __ATOMIC_RELAXED);
     epa_t e;
     {   /* start tetrahedron: two support points along a fixed skew direction and its opposite, the support point farthest from
@@ -1198,7 +1202,6 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
         const double ha = fabs(dot3(n3, ra)), hb = fabs(dot3(n3, rb));
         memcpy(e.v[3], ha >= hb ? pa3 : pb3, 24);
         const double hh = ha >= hb ? ha : hb;
-        if (getenv("NBK_EPA_DEBUG")) fprintf(stderr, "epa start l1 %.3g l3 %.3g hh %.3g kinds %d %d\n", l1, l3, hh, A->kind, Bc->kind);
         if (!(hh * hh > 1e-24 * l3 * l1)) { __atomic_add_fetch(&g_epa_fail, 1, __ATOMIC_RELAXED); return 0; }
     }
     for (int c = 0; c < 3; ++c) e.ref[c] = 0.25 * (((e.v[0][c] + e.v[1][c]) + e.v[2][c]) + e.v[3][c]);
@@ -1214,12 +1217,13 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
         if (bf < 0) break;
         const double n[3] = {e.fn[bf][0], e.fn[bf][1], e.fn[bf][2]};
         const double d = e.fd[bf];
+        if (decide && d > x) return 2;
         double w[3];
         mink_support(A, Bc, n, w);
         const double dw = dot3(n, w);
-        if (getenv("NBK_EPA_DEBUG")) fprintf(stderr, "epa it %d nf %d nv %d face %d d %.6g dw %.6g\n", it, e.nf, e.nv, bf, d, dw);
         if (dw < best_up) { best_up = dw; best_n[0] = n[0]; best_n[1] = n[1]; best_n[2] = n[2]; }
         __atomic_add_fetch(&g_epa_iters, 1, __ATOMIC_RELAXED);
+        if (decide && best_up <= x) return 3;
         if (dw - d <= EPA_TOL * (1.0 + fabs(dw))) { ok = 1; break; }       /* (d < 0 here: the origin is outside M by -d: a contact within rounding) */
         if (e.nv >= EPA_MAXV) break;
         const int wi = e.nv++;
@@ -1250,6 +1254,7 @@ static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *n
     normal[0] = -best_n[0]; normal[1] = -best_n[1]; normal[2] = -best_n[2];      /* from B to A */
     return 1;
 }
+static int epa_depth(const core_t *A, const core_t *Bc, double *depth, double *normal) { return epa_run(A, Bc, depth, normal, 0, 0.0); }
 void orc_epa_stats(long long *out, int reset) {
     out[0] = g_epa_calls; out[1] = g_epa_fail; out[2] = g_epa_iters;
     if (reset) { g_epa_calls = 0; g_epa_fail = 0; g_epa_iters = 0; }
@@ -1262,6 +1267,22 @@ static double overlap_depth_exact(const core_t *A, const core_t *Bc, double *nor
         if (epa_depth(A, Bc, &de, ne) && de < depth) { depth = de; normal[0] = ne[0]; normal[1] = ne[1]; normal[2] = ne[2]; }
     }
     return depth;
+}
+
+/* is the exact depth of two overlapping cores larger than x?  = (overlap_depth_exact > x), without running EPA to the end:
+ * the family's value is an upper bound (not deeper than x: done), exact without a cylinder / hull core, and EPA stops at its
+ * first certain answer */
+static int overlap_deeper_than(const core_t *A, const core_t *Bc, double x) {
+    double nrm[3];
+    const double fam = overlap_depth(A, Bc, nrm);
+    if (!(fam > x)) return 0;
+    if (!(A->kind == K_CYL || A->kind == K_HULL || Bc->kind == K_CYL || Bc->kind == K_HULL)) return 1;
+    double de = 0.0, ne[3];
+    const int r = epa_run(A, Bc, &de, ne, 1, x);
+    if (r == 2) return 1;
+    if (r == 3) return 0;
+    if (r == 1) return de > x;
+    return 1;                                  /* no answer from EPA: the family's value stands */
 }
 
 static double core_bound_radius(const core_t *s) {

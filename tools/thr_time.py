@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','/root/repo'))
 from numbotics_amd.physics import World
 from numbotics_amd.scenes import build_scene, sample_q
 World()
-arm, chain, obs = build_scene(sys.argv[1] if len(sys.argv)>1 else 'c2')
+arm, chain, obs = build_scene(sys.argv[1] if len(sys.argv)>1 else 'c2', bullet_margins=not (len(sys.argv) > 2 and sys.argv[2] == 'sharp'))   # [scene] [sharp]
 sm, dev = arm._scene_device()
 q = torch.from_numpy(sample_q(chain, 1_000_000, seed=1)).cuda()
 for thr in (0.0, 1e-6, 0.01, -0.002):
