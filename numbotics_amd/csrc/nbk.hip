@@ -2102,6 +2102,7 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
     const int qrows = f32_qrows(nq, S);
     const int qcap = qrows * (WAVE * 2);                                          // queue entries the slab holds
     float* lds_fr = reinterpret_cast<float*>(lds_raw + WAVE * qrows);             // saved frames [12*slots][64] float
+    float* lds_zp = lds_fr + WAVE * 12 * m.frame_slots + 4;                        // z of the slots of NBK_ZMASK [S][64] (see cz below)
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
     // launch-uniform tables (k_prepare_f32): scalar loads
     const FTab ft = ftab_view(tab, W);
@@ -2152,13 +2153,21 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
     float cxa[S], cya[S], cza[S];
 #define cx(i_) cxa[i_]
 #define cy(i_) cya[i_]
-#define cz(i_) cza[i_]
+    // (the 36 centre floats of 12 slots do not all fit next to the row arithmetic at 5 waves per SIMD: the compiler spilled one z pair
+    // -- 8 MB of scratch writes per 1e6 configurations --; the z of slots 4 and 5 stay in LDS instead and are read where they are used)
+#ifndef NBK_ZMASK
+#define NBK_ZMASK 4u               // bit p: the z of slots 2p, 2p + 1 live in LDS
+#endif
+#define NBK_ZL(i_) (((NBK_ZMASK >> ((i_) >> 1)) & 1u) != 0u)
+#define cz(i_) (NBK_ZL(i_) ? lds_zp[(i_) * WAVE + lane] : cza[i_])
 #define cx2v(i_) V2f{cxa[2 * (i_)], cxa[2 * (i_) + 1]}
 #define cy2v(i_) V2f{cya[2 * (i_)], cya[2 * (i_) + 1]}
-#define cz2v(i_) V2f{cza[2 * (i_)], cza[2 * (i_) + 1]}
+#define cz2v(i_) (NBK_ZL(2 * (i_)) ? V2f{lds_zp[(2 * (i_)) * WAVE + lane], lds_zp[(2 * (i_) + 1) * WAVE + lane]} : V2f{cza[2 * (i_)], cza[2 * (i_) + 1]})
     float rmax = m.f_reach, qabs = 0.0f;
 #pragma unroll
     for (int i = 0; i < S; ++i) { cxa[i] = 0.0f; cya[i] = 0.0f; cza[i] = 0.0f; }
+#pragma unroll
+    for (int i = 0; i < S; ++i) if (NBK_ZL(i)) lds_zp[i * WAVE + lane] = 0.0f;
     if (m.f_chain) {
         // ---- serial chains of at most 8 joints (every arm): the joint loop is unrolled at COMPILE time, so every per-joint table sits
         // at a static offset (scalar loads the compiler issues early, no dependent load -> wait -> branch chains, no address
@@ -2215,7 +2224,10 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
         }
 #undef NBK_CHAIN_SHAPES
 #pragma unroll
-        for (int i = 0; i < S; ++i) cza[i] = i < m.n_rshapes ? lds_cz[i * WAVE + lane] : 0.0f;
+        for (int i = 0; i < S; ++i) {
+            const float zi = i < m.n_rshapes ? lds_cz[i * WAVE + lane] : 0.0f;
+            if (NBK_ZL(i)) lds_zp[i * WAVE + lane] = zi; else cza[i] = zi;
+        }
     } else {
         XfF bpose;
         const float* bp = m.f_tab + m.f_base;
@@ -4564,7 +4576,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
         const size_t qrows_f = (size_t)f32_qrows(m->d.n_q, S <= 8 ? 8 : (S <= 12 ? 12 : 16));
-        const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16;
+        const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16 + sizeof(float) * WAVE * 16;   // (+ the z coordinates of the slots k_broad_f32 keeps in LDS)
         unsigned long long* count_next = nullptr;
         if (use_reg && f32) {
             if (internal && iw->ready && !iw->captured && iw->thr == threshold) {

@@ -5,7 +5,7 @@ if len(sys.argv) > 1: _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from numbotics_amd.physics import World
 from numbotics_amd.scenes import build_scene, sample_q
 World()
-arm, chain, obs = build_scene('c2')
+arm, chain, obs = build_scene(sys.argv[2] if len(sys.argv) > 2 else 'c2')     # [lib.so] [scene]
 sm, dev = arm._scene_device()
 q5 = torch.from_numpy(sample_q(chain, 10071, seed=31)).cuda()
 def t(fn, n=10):
