@@ -2088,6 +2088,11 @@ __device__ unsigned long long g_broad_prof[8];
 #ifndef NBK_BF32_WAVES
 #define NBK_BF32_WAVES 5
 #endif
+#ifndef NBK_ZMASK
+#define NBK_ZMASK 4u               // bit p: the z coordinates of slots 2p, 2p + 1 live in LDS, not in registers (see cz in the kernel)
+#define NBK_ZFIRST 4               // first such slot and how many slots from there the LDS area backs
+#define NBK_ZSLOTS 2
+#endif
 template <int S, bool WH>      // WH: the world holds hulls (scenes without them get a kernel without that branch: primitive scenes lost 8 us to it)
 __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, EdgeSrc es, const double* __restrict__ q, int64_t B, double thr,
                                                    uint64_t* __restrict__ mask_bits, uint8_t* __restrict__ mask_bytes,
@@ -2102,7 +2107,7 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
     const int qrows = f32_qrows(nq, S);
     const int qcap = qrows * (WAVE * 2);                                          // queue entries the slab holds
     float* lds_fr = reinterpret_cast<float*>(lds_raw + WAVE * qrows);             // saved frames [12*slots][64] float
-    float* lds_zp = lds_fr + WAVE * 12 * m.frame_slots + 4;                        // z of the slots of NBK_ZMASK [S][64] (see cz below)
+    float* lds_zp = lds_fr + WAVE * 12 * m.frame_slots + 4 - NBK_ZFIRST * WAVE;    // z of the slots of NBK_ZMASK, indexed by slot: [NBK_ZFIRST .. NBK_ZFIRST + NBK_ZSLOTS) are backed (see cz below)
     unsigned* lds_queue = reinterpret_cast<unsigned*>(lds_raw);
     // launch-uniform tables (k_prepare_f32): scalar loads
     const FTab ft = ftab_view(tab, W);
@@ -2155,9 +2160,6 @@ __global__ __launch_bounds__(64, NBK_BF32_WAVES) void k_broad_f32(DevModel m, Ed
 #define cy(i_) cya[i_]
     // (the 36 centre floats of 12 slots do not all fit next to the row arithmetic at 5 waves per SIMD: the compiler spilled one z pair
     // -- 8 MB of scratch writes per 1e6 configurations --; the z of slots 4 and 5 stay in LDS instead and are read where they are used)
-#ifndef NBK_ZMASK
-#define NBK_ZMASK 4u               // bit p: the z of slots 2p, 2p + 1 live in LDS
-#endif
 #define NBK_ZL(i_) (((NBK_ZMASK >> ((i_) >> 1)) & 1u) != 0u)
 #define cz(i_) (NBK_ZL(i_) ? lds_zp[(i_) * WAVE + lane] : cza[i_])
 #define cx2v(i_) V2f{cxa[2 * (i_)], cxa[2 * (i_) + 1]}
@@ -4576,7 +4578,7 @@ static int32_t launch_two_kernel_impl(const nbk_model* m, const PairCounts& pc, 
         float* ftab = reinterpret_cast<float*>(static_cast<char*>(workspace) + WS_COUNTERS);
         // LDS of the float32 kernel: q slab (later the item queue) + saved frames
         const size_t qrows_f = (size_t)f32_qrows(m->d.n_q, S <= 8 ? 8 : (S <= 12 ? 12 : 16));
-        const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16 + sizeof(float) * WAVE * 16;   // (+ the z coordinates of the slots k_broad_f32 keeps in LDS)
+        const size_t lds_f = sizeof(double) * WAVE * qrows_f + sizeof(float) * WAVE * 12 * (size_t)m->d.frame_slots + 16 + sizeof(float) * WAVE * NBK_ZSLOTS;   // (+ the z coordinates of the slots k_broad_f32 keeps in LDS)
         unsigned long long* count_next = nullptr;
         if (use_reg && f32) {
             if (internal && iw->ready && !iw->captured && iw->thr == threshold) {
