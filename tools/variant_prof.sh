@@ -13,7 +13,7 @@ import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"].split("(")[0]
     if "k_broad" in n or "k_narrow" in n:
-        print("   %-28s calls %3s avg %8.1f us" % (n[-28:], r["Calls"], float(r["AverageNs"]) / 1e3))
+        print("   %-28s calls %3s avg %8.1f us  min %8.1f  max %8.1f" % (n[-28:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
   else echo "   (no kernel_stats.csv)"; fi
 done
