@@ -804,17 +804,26 @@ __device__ __attribute__((noinline)) int epa_depth_copy(Core A, Core Bc, double*
 // (oracle: overlap_deeper_than)
 __device__ __attribute__((noinline)) bool overlap_deeper_copy(Core A, Core Bc, double x) {
     double nrm[3];
-    double fam;
-    const bool lds_a = A.rad > 0.0 && A.kind == K_HULL, lds_b = Bc.rad > 0.0 && Bc.kind == K_HULL;
-    if (lds_a || lds_b) fam = overlap_depth<true>(A, Bc, nrm);
-    else fam = overlap_depth<false>(A, Bc, nrm);
-    if (!(fam > x)) return false;
-    if (!(A.kind == K_CYL || A.kind == K_HULL || Bc.kind == K_CYL || Bc.kind == K_HULL)) return true;
+    // a hull's family scans faces x vertices: there EPA goes first and the family is consulted only when EPA leaves the question open;
+    // everywhere else the family is a handful of axes and settles most items before a polytope is built
+    const bool hull = A.kind == K_HULL || Bc.kind == K_HULL;
+    if (!hull) {
+        const double fam = overlap_depth<false>(A, Bc, nrm);
+        if (!(fam > x)) return false;
+        if (!(A.kind == K_CYL || Bc.kind == K_CYL)) return true;
+    }
     // (hull cores staged in LDS keep their LDS byte address in `rad`: the support routine ignores it)
     double o[4];
     const int r = epa_depth_copy(A, Bc, o, 1, x);
     if (r == 2) return true;
     if (r == 3) return false;
+    if (hull) {
+        double fam;
+        const bool lds_a = A.rad > 0.0 && A.kind == K_HULL, lds_b = Bc.rad > 0.0 && Bc.kind == K_HULL;
+        if (lds_a || lds_b) fam = overlap_depth<true>(A, Bc, nrm);
+        else fam = overlap_depth<false>(A, Bc, nrm);
+        if (!(fam > x)) return false;
+    }
     if (r == 1) return o[0] > x;
     return true;                       // no answer from EPA: the family's value stands
 }

@@ -1274,13 +1274,22 @@ static double overlap_depth_exact(const core_t *A, const core_t *Bc, double *nor
  * first certain answer */
 static int overlap_deeper_than(const core_t *A, const core_t *Bc, double x) {
     double nrm[3];
-    const double fam = overlap_depth(A, Bc, nrm);
-    if (!(fam > x)) return 0;
-    if (!(A->kind == K_CYL || A->kind == K_HULL || Bc->kind == K_CYL || Bc->kind == K_HULL)) return 1;
+    /* a hull's family scans faces x vertices: there EPA goes first and the family is consulted only when EPA leaves the question open;
+     * everywhere else the family is a handful of axes and settles most items before a polytope is built */
+    const int hull = A->kind == K_HULL || Bc->kind == K_HULL;
+    if (!hull) {
+        const double fam = overlap_depth(A, Bc, nrm);
+        if (!(fam > x)) return 0;
+        if (!(A->kind == K_CYL || Bc->kind == K_CYL)) return 1;
+    }
     double de = 0.0, ne[3];
     const int r = epa_run(A, Bc, &de, ne, 1, x);
     if (r == 2) return 1;
     if (r == 3) return 0;
+    if (hull) {
+        const double fam = overlap_depth(A, Bc, nrm);
+        if (!(fam > x)) return 0;
+    }
     if (r == 1) return de > x;
     return 1;                                  /* no answer from EPA: the family's value stands */
 }
