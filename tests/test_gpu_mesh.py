@@ -14,11 +14,14 @@ from numbotics_amd._lib import debug_option
 from test_gpu_parity import assert_bitwise, fused_path, torch_cuda      # noqa: F401  (fixture)
 
 
+@pytest.mark.parametrize("margins", [True, False], ids=["bullet", "sharp"])
 @pytest.mark.parametrize("scene", ["c2m", "c5m"])
-def test_mesh_validity_through_all_three_paths(fresh_world, scene, torch_cuda):
+def test_mesh_validity_through_all_three_paths(fresh_world, scene, margins, torch_cuda):
+    """Default shape mode and sharp hulls: with sharp hulls a negative threshold reaches the "deeper than -tc?" predicate of hull pairs
+    (EPA's early exits first, the axis family only when EPA leaves the question open)."""
     import os
     torch = torch_cuda
-    arm, chain, obs = build_scene(scene)
+    arm, chain, obs = build_scene(scene, bullet_margins=margins)
     sm = arm.scene_model()
     assert (sm.rshape_type == 5).sum() == 10
     orc = Oracle(sm)
