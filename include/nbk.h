@@ -95,8 +95,9 @@ typedef struct {
     int32_t n_hulls;
     const int32_t *hull_vert_begin;  /* [H+1] */
     const double *hull_verts;        /* [NV][3] */
-    const int32_t *hull_face_begin;  /* [H+1]; a hull may have no planes (flat point set): distances stay exact, the
-                                        penetration depth then falls back to the other shape's axes and the centre line */
+    const int32_t *hull_face_begin;  /* [H+1]; a hull may have no planes (flat point set): distances stay exact; the
+                                        penetration depth is EPA's either way, without planes its fallback (when EPA gives no
+                                        answer) has only the other shape's axes and the centre line */
     const double *hull_planes;       /* [NF][4] unit outward normal n and offset d: inside n.x <= d.  nbk_model_create checks
                                         ||n|^2 - 1| <= 1e-9 and n.v <= d (+1e-9 relative) for every vertex of the hull and
                                         returns NBK_ERR_INVALID otherwise: the broadphase certifies collisions from the ball
