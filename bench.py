@@ -191,7 +191,8 @@ def main():
             if wd.numel() != w4:
                 pad4.zero_(); pad4[:wd.numel()].copy_(wd); wd = pad4
             if overlapped and args.backend == "nccl":
-                return dist.all_gather_into_tensor(gath4[i & 1], wd.contiguous(), async_op=True)
+                # (a private copy of the 156 KB of words: the next step rewrites its source while this gather may still read it)
+                return dist.all_gather_into_tensor(gath4[i & 1], wd.clone().contiguous(), async_op=True)
             allgather_mask_words(wd, gath4[i & 1])
             return None
 
