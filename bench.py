@@ -394,9 +394,19 @@ def main():
             pin_w.copy_(wds, non_blocking=True)
         e_pin = timed(lambda: e2e(pin_q), reps=10)
         e_page = timed(lambda: e2e(page_q), reps=10)
+        # ... and with q drawn on the device (scenes.sample_q_device): what a sampling planner pays when q never crosses PCIe
+        from numbotics_amd.scenes import sample_q_device
+
+        def e2e_dev():
+            sample_q_device(chain, B, seed=7, out=dq)
+            wds = dev.validity(dq, 0.0, packed=True)
+            pin_w.copy_(wds, non_blocking=True)
+        e_dev = timed(e2e_dev, reps=10)
         out["end_to_end"] = {"what": "H2D of q + nbk_validity_batch + D2H of the packed mask, per step", "batch": B,
                              "pinned": dict(e_pin, configs_per_s=B / (e_pin["median_ms"] * 1e-3)),
                              "pageable": dict(e_page, configs_per_s=B / (e_page["median_ms"] * 1e-3)),
+                             "sampled_on_device": dict(e_dev, configs_per_s=B / (e_dev["median_ms"] * 1e-3),
+                                                       what="q ~ U(limits) drawn on the device (torch generator) + the step + D2H of the mask"),
                              "h2d_bytes": B * 8.0 * chain.dof, "d2h_bytes": n_words * 8.0}
         del pin_q, dq, page_q
 

@@ -82,3 +82,15 @@ def sample_q(chain, B: int, seed: int = 1, margin: float = 0.0):
     rng = np.random.default_rng(seed)
     lim = chain.joint_limits
     return rng.uniform(lim[:, 0] + margin, lim[:, 1] - margin, (B, chain.dof))
+
+
+def sample_q_device(chain, B: int, seed: int = 1, margin: float = 0.0, device="cuda", out=None):
+    """The same distribution drawn ON the device (torch's generator: not the NumPy stream of ``sample_q``): a float64 (B, dof)
+    CUDA tensor, so that a sampling planner never moves q over PCIe -- 56 MB per 1e6 configurations cost 8 x the validity step."""
+    import torch
+    lim = torch.as_tensor(np.asarray(chain.joint_limits, dtype=np.float64), device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    u = torch.rand((B, chain.dof), dtype=torch.float64, device=device, generator=g) if out is None else out.uniform_(0.0, 1.0, generator=g)
+    lo = lim[:, 0] + margin
+    return u.mul_(lim[:, 1] - margin - lo).add_(lo)

@@ -107,6 +107,24 @@ def test_jacobian_bitwise_and_golden(kinova, g3, golden_meta, torch_cuda):
     assert np.array_equal(arm.jacobian(q[:4], "base_link"), np.zeros((4, 6, 7)))  # arm.py:455-457
 
 
+def test_configurations_sampled_on_the_device(kinova, torch_cuda):
+    """scenes.sample_q_device: q ~ U(limits) as a CUDA tensor (no PCIe); the mask of those q equals the oracle's on the same values."""
+    from numbotics_amd.scenes import sample_q_device
+    arm, chain, _ = kinova
+    lim = np.asarray(chain.joint_limits, dtype=np.float64)
+    q = sample_q_device(chain, 30000, seed=5)
+    assert q.is_cuda and q.dtype == torch_cuda.float64 and q.shape == (30000, chain.dof)
+    qh = q.cpu().numpy()
+    assert (qh >= lim[:, 0]).all() and (qh <= lim[:, 1]).all()
+    assert np.abs(qh.mean(axis=0) - lim.mean(axis=1)).max() < 0.05 * (lim[:, 1] - lim[:, 0]).max()
+    assert torch_cuda.equal(q, sample_q_device(chain, 30000, seed=5)) and not torch_cuda.equal(q, sample_q_device(chain, 30000, seed=6))
+    buf = torch_cuda.empty((30000, chain.dof), dtype=torch_cuda.float64, device="cuda")
+    assert sample_q_device(chain, 30000, seed=5, out=buf).data_ptr() == buf.data_ptr() and torch_cuda.equal(buf, q)
+    mask = arm.in_collision(q)
+    assert mask.is_cuda
+    assert np.array_equal(mask.cpu().numpy(), Oracle(arm.scene_model()).validity(qh, 0.0))
+
+
 def test_fk_and_jacobian_q_paths_agree(kinova, g3, torch_cuda):
     """k_fk / k_jacobian_reg read q straight into registers for n_q <= 8; the LDS-staged form (robots beyond 8 DoF, or the
     ``fk_lds_q`` switch) must give the same bits, ragged block tails included."""
