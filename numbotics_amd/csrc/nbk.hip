@@ -3084,6 +3084,9 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     for (int p = p_lo; p < p_hi; ++p) {
         Core A, Bc;
         load_pair(m, lds_s, p, lane, A, Bc);
+        // (every lane holds the same two shapes here: a hull's vertices go through the scalar cache, see core_support)
+        if (A.kind == K_HULL) A.rad = -1.0;
+        if (Bc.kind == K_HULL) Bc.rad = -1.0;
         double wit[9];
         double fam = -1.0;
         const double d = cores_distance<(MODE >= 2), (MODE >= 1)>(A, Bc, wit, &fam);

@@ -190,9 +190,22 @@ NBK_DEV void core_support(const Core& s, const double* d, double* o) {
         case K_HULL: {
             // direction in local coordinates, first maximum over the vertex list, that vertex back to the world
             const double dl0 = dot3(d, s.ax[0]), dl1 = dot3(d, s.ax[1]), dl2 = dot3(d, s.ax[2]);
-            const int hn = hull_hn(s);
             double v0, v1, v2;
-            hull_first_max(hull_hv(s), hn, dl0, dl1, dl2, v0, v1, v2);       // (k_narrow*: hv may be a flat address of the LDS copy)
+            if (s.rad < 0.0) {
+                // rad < 0 (set by the pair loop of k_distances): every lane of the wave holds THIS hull, only the poses differ -- the
+                // vertex list is read through the scalar cache (constant address space, uniform pointer and count) instead of sixty-four
+                // identical vector loads per coordinate; same comparisons, same vertex
+                typedef const __attribute__((address_space(4))) double* ConstDoubleP;
+                const unsigned long long pu = __builtin_bit_cast(unsigned long long, s.h[0]);
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)pu);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(pu >> 32));
+                const ConstDoubleP hvu = (ConstDoubleP)(((unsigned long long)hi << 32) | lo);
+                const int hnu = __builtin_amdgcn_readfirstlane(hull_hn(s));
+                hull_first_max(hvu, hnu, dl0, dl1, dl2, v0, v1, v2);
+            } else {
+                const int hn = hull_hn(s);
+                hull_first_max(hull_hv(s), hn, dl0, dl1, dl2, v0, v1, v2);       // (k_narrow*: hv may be a flat address of the LDS copy)
+            }
             copy3(s.c, o);
             axpy3(v0, s.ax[0], o, o);
             axpy3(v1, s.ax[1], o, o);
