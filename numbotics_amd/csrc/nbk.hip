@@ -3012,12 +3012,19 @@ NBK_DEV void prox_row(const DevModel& m, const double* lds_jz, int col, int p, c
 
 constexpr int EPAQ_CAP = 128;                  // (lane, pair) items waiting for their EPA pass, per wave
 
+// MODE >= 1: TWO waves per workgroup share the parked cores of the block's 64 configurations (lane = configuration in both) and take
+// every other pair of the workgroup's slice: a robot whose parked rows fill 70+ KB fits two workgroups per CU, and the kernel's
+// 256 registers allow four waves -- with one-wave workgroups half the SIMDs idled (mesh scene: records 7.3 -> see DESIGN.md).  Both
+// waves stage q and sweep the tree themselves (identical values to identical LDS addresses; no hand-over to wait for).
+constexpr int EPAQ_DOUBLES = EPAQ_CAP + EPAQ_CAP / 2;        // one wave's EPA queue: depths [EPAQ_CAP] double, items [EPAQ_CAP] unsigned
 template <int MODE>
-__global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __restrict__ q, int64_t B,
+__global__ __launch_bounds__(MODE == 0 ? 64 : 128) void k_distances(DevModel m, const double* __restrict__ q, int64_t B,
                                                    double* __restrict__ out_d, int32_t* __restrict__ out_i,
                                                    double* __restrict__ out_w, double* __restrict__ out_j = nullptr) {
     extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x % WAVE;
+    const int wave = MODE == 0 ? 0 : (int)(threadIdx.x / WAVE);
+    constexpr int NWAVE = MODE == 0 ? 1 : 2;
     const int64_t base = (int64_t)blockIdx.x * WAVE;
     double* lds_q = lds;
     double* lds_s = lds_q + WAVE * m.n_q;
@@ -3032,7 +3039,7 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     // MODE >= 1: overlapping cores whose exact depth needs EPA (a cylinder or a hull) get the axis-family value first and are queued
     // (lane, pair, family depth) in the LDS tail the validity path uses for its own queue; the queue is drained one item per lane --
     // 64 polytopes grow side by side instead of one lane's while 63 wait -- and a better (smaller) depth overwrites the record.
-    double* epaq_depth = lds_fr + WAVE * 12 * m.frame_slots + (MODE == 3 ? WAVE * 6 * m.n_joints : 0);
+    double* epaq_depth = lds_fr + WAVE * 12 * m.frame_slots + (MODE == 3 ? WAVE * 6 * m.n_joints : 0) + wave * EPAQ_DOUBLES;
     unsigned* epaq_item = reinterpret_cast<unsigned*>(epaq_depth + EPAQ_CAP);
     int epaq_n = 0;
     auto epaq_drain = [&]() {
@@ -3081,7 +3088,7 @@ __global__ __launch_bounds__(64) void k_distances(DevModel m, const double* __re
     // wave per 64 samples on a 1 024-SIMD chip and walk 44 GJK distances one after the other
     const int p_lo = (MODE == 0) ? 0 : (int)(((long long)m.n_pairs * blockIdx.y) / gridDim.y);
     const int p_hi = (MODE == 0) ? m.n_pairs : (int)(((long long)m.n_pairs * (blockIdx.y + 1)) / gridDim.y);
-    for (int p = p_lo; p < p_hi; ++p) {
+    for (int p = p_lo + wave; p < p_hi; p += NWAVE) {
         Core A, Bc;
         load_pair(m, lds_s, p, lane, A, Bc);
         // (every lane holds the same two shapes here: a hull's vertices go through the scalar cache, see core_support)
@@ -4747,6 +4754,9 @@ static inline unsigned pair_groups(const nbk_model* m, int64_t B) {
     return (unsigned)(g < 1 ? 1 : g);
 }
 
+// the two-wave workgroups of k_distances<1..3>: half as many groups for the same number of waves
+static inline unsigned pair_groups2(const nbk_model* m, int64_t B) { const unsigned g = pair_groups(m, B); return g > 1 ? (g + 1) / 2 : 1; }
+
 int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double* min_dist, int32_t* argmin, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || min_dist == nullptr))) return NBK_ERR_INVALID;
     NBK_DEVICE(m);
@@ -4767,13 +4777,13 @@ int32_t nbk_closest_batch(const nbk_model* m, const double* q, int64_t B, double
 int32_t nbk_pair_distances_batch(const nbk_model* m, const double* q, int64_t B, double* dist, double* witness, void* stream) {
     if (m == nullptr || B < 0 || (B > 0 && (q == nullptr || dist == nullptr))) return NBK_ERR_INVALID;
     NBK_DEVICE(m);
-    if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
+    if (!m->parked_ok || collide_lds(m) + 8 * EPAQ_DOUBLES > 160 * 1024) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
     if (witness != nullptr)
-        hipLaunchKernelGGL(k_distances<2>, dim3(blocks_for(B), pair_groups(m, B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
+        hipLaunchKernelGGL(k_distances<2>, dim3(blocks_for(B), pair_groups2(m, B)), dim3(2 * WAVE), collide_lds(m) + 8 * EPAQ_DOUBLES, (hipStream_t)stream, m->d, q, B, dist,
                            (int32_t*)nullptr, witness);
     else
-        hipLaunchKernelGGL(k_distances<1>, dim3(blocks_for(B), pair_groups(m, B)), dim3(WAVE), collide_lds(m), (hipStream_t)stream, m->d, q, B, dist,
+        hipLaunchKernelGGL(k_distances<1>, dim3(blocks_for(B), pair_groups2(m, B)), dim3(2 * WAVE), collide_lds(m) + 8 * EPAQ_DOUBLES, (hipStream_t)stream, m->d, q, B, dist,
                            (int32_t*)nullptr, (double*)nullptr);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
@@ -4785,9 +4795,9 @@ int32_t nbk_proximity_jacobian_batch(const nbk_model* m, const double* q, int64_
     NBK_DEVICE(m);
     if (!m->parked_ok) return NBK_ERR_UNSUPPORTED;
     if (B == 0 || m->n_pairs == 0) return NBK_OK;
-    const size_t lds = collide_lds(m) + sizeof(double) * WAVE * 6 * (size_t)m->n_joints;
+    const size_t lds = collide_lds(m) + sizeof(double) * WAVE * 6 * (size_t)m->n_joints + 8 * EPAQ_DOUBLES;
     if (lds > 160 * 1024) return NBK_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_distances<3>, dim3(blocks_for(B), pair_groups(m, B)), dim3(WAVE), lds, (hipStream_t)stream, m->d, q, B, dist, (int32_t*)nullptr,
+    hipLaunchKernelGGL(k_distances<3>, dim3(blocks_for(B), pair_groups2(m, B)), dim3(2 * WAVE), lds, (hipStream_t)stream, m->d, q, B, dist, (int32_t*)nullptr,
                        witness, jrows);
     NBK_HIP(hipGetLastError());
     return NBK_OK;
